@@ -1,0 +1,205 @@
+"""ctypes binding of libboxlcd_hip.so (include/boxlcd.h).  Fails loudly: no library or no GPU -> RuntimeError."""
+import ctypes as C
+import os
+import numpy as np
+from .scene import SceneDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libboxlcd_hip.so')
+BODY_F, JOINT_F, PAIR_F = 12, 5, 18
+
+SYMBOLS = {
+    'blcd_version': (C.c_int, []),
+    'blcd_last_error': (C.c_char_p, []),
+    'blcd_device_count': (C.c_int, []),
+    'blcd_create': (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    'blcd_destroy': (C.c_int, [C.c_void_p]),
+    'blcd_num_envs': (C.c_int, [C.c_void_p]),
+    'blcd_num_pairs': (C.c_int, [C.c_void_p]),
+    'blcd_pair_table': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'blcd_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'blcd_set_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'blcd_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'blcd_get_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'blcd_render_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'blcd_get_poses': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'blcd_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
+    'blcd_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    'blcd_get_faults': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'blcd_sync': (C.c_int, [C.c_void_p]),
+    'blcd_stream': (C.c_void_p, [C.c_void_p]),
+    'blcd_last_kernel_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    'blcd_debug_world_step': (C.c_int, [C.c_void_p, C.c_int32]),
+    'blcd_debug_set_motor_speeds': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'blcd_debug_dump': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'blcd_debug_sincos': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
+    'blcd_debug_mass_data': (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.c_float, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+  """dlopen the HIP library and bind every symbol include/boxlcd.h declares.  Raises RuntimeError if it is missing."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(hipcc --offload-arch=gfx950). boxlcd_amd has no CPU fallback.')
+  lib = C.CDLL(LIB_PATH)
+  for name, (res, args) in SYMBOLS.items():
+    fn = getattr(lib, name)  # AttributeError if the library does not export it
+    fn.restype, fn.argtypes = res, args
+  _lib = lib
+  return lib
+
+
+def _check(rc):
+  if rc != 0:
+    msg = load().blcd_last_error()
+    raise RuntimeError(f'boxlcd_hip error {rc}: {msg.decode() if msg else "?"}')
+
+
+def _ptr(x):
+  """numpy array -> host pointer; torch tensor -> its data_ptr (device or host); None -> NULL."""
+  if x is None:
+    return None
+  if hasattr(x, 'data_ptr'):
+    return C.c_void_p(x.data_ptr())
+  return x.ctypes.data_as(C.c_void_p)
+
+
+class Handle:
+  """One blcd_handle: n_envs environments of one scene on one GPU."""
+
+  def __init__(self, desc, n_envs, device=0):
+    self.lib = load()
+    self.desc = desc
+    self.n = int(n_envs)
+    self.nb, self.nj = desc.n_bodies, desc.n_joints
+    self.n_obs, self.n_act = desc.n_obs, desc.n_act
+    self.h, self.w = desc.lcd_h, desc.lcd_w
+    out = C.c_void_p()
+    _check(self.lib.blcd_create(C.byref(desc), self.n, int(device), C.byref(out)))
+    self._h = out
+    self.n_pairs = self.lib.blcd_num_pairs(self._h)
+
+  def close(self):
+    if self._h is not None:
+      self.lib.blcd_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  def pair_table(self):
+    t = np.zeros((self.n_pairs, 2), np.int32)
+    _check(self.lib.blcd_pair_table(self._h, _ptr(t)))
+    return t
+
+  def reset(self, idxs, poses, shape_sel=None):
+    n = self.n if idxs is None else len(idxs)
+    if idxs is not None:
+      idxs = np.ascontiguousarray(idxs, dtype=np.int32)
+    if not hasattr(poses, 'data_ptr'):
+      poses = np.ascontiguousarray(poses, dtype=np.float32)
+      assert poses.shape == (n, self.nb, 3), poses.shape
+    if shape_sel is not None and not hasattr(shape_sel, 'data_ptr'):
+      shape_sel = np.ascontiguousarray(shape_sel, dtype=np.int32)
+    _check(self.lib.blcd_reset(self._h, _ptr(idxs), n, _ptr(poses), _ptr(shape_sel)))
+
+  def set_poses(self, idxs, poses, mask=None):
+    n = self.n if idxs is None else len(idxs)
+    if idxs is not None:
+      idxs = np.ascontiguousarray(idxs, dtype=np.int32)
+    poses = np.ascontiguousarray(poses, dtype=np.float32)
+    assert poses.shape == (n, self.nb, 3), poses.shape
+    if mask is not None:
+      mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    _check(self.lib.blcd_set_poses(self._h, _ptr(idxs), n, _ptr(poses), _ptr(mask)))
+
+  def step(self, actions=None, n_steps=1):
+    if actions is not None and not hasattr(actions, 'data_ptr'):
+      actions = np.ascontiguousarray(actions, dtype=np.float32)
+      assert actions.shape == (self.n, self.n_act), actions.shape
+    _check(self.lib.blcd_step(self._h, _ptr(actions), int(n_steps)))
+
+  def rollout(self, actions, T, lcd_out=None, obs_out=None):
+    if actions is not None and not hasattr(actions, 'data_ptr'):
+      actions = np.ascontiguousarray(actions, dtype=np.float32)
+      assert actions.shape == (T, self.n, self.n_act), actions.shape
+    _check(self.lib.blcd_rollout(self._h, _ptr(actions), int(T), _ptr(lcd_out), _ptr(obs_out)))
+
+  def get_obs(self, dtype=np.float32, lcd=True):
+    fs = None
+    if dtype is not None:
+      fs = np.zeros((self.n, self.n_obs), dtype)
+    img = np.zeros((self.n, self.h, self.w), np.uint8) if lcd else None
+    _check(self.lib.blcd_get_obs(self._h, _ptr(fs), 1 if dtype == np.float64 else 0, _ptr(img)))
+    return fs, img
+
+  def get_obs_into(self, fs, lcd):
+    """device (torch) or host buffers, float32 obs."""
+    _check(self.lib.blcd_get_obs(self._h, _ptr(fs), 0, _ptr(lcd)))
+
+  def render_poses(self, poses, shape_sel=None):
+    poses = np.ascontiguousarray(poses, dtype=np.float32)
+    m = poses.shape[0]
+    assert poses.shape == (m, self.nb, 3)
+    if shape_sel is not None:
+      shape_sel = np.ascontiguousarray(shape_sel, dtype=np.int32)
+    img = np.zeros((m, self.h, self.w), np.uint8)
+    _check(self.lib.blcd_render_poses(self._h, _ptr(poses), _ptr(shape_sel), m, _ptr(img)))
+    return img
+
+  def get_poses(self):
+    p = np.zeros((self.n, self.nb, 4), np.float32)
+    _check(self.lib.blcd_get_poses(self._h, _ptr(p)))
+    return p
+
+  def get_state(self):
+    size = C.c_size_t(0)
+    _check(self.lib.blcd_get_state(self._h, None, C.byref(size)))
+    blob = np.zeros(size.value, np.uint8)
+    _check(self.lib.blcd_get_state(self._h, _ptr(blob), C.byref(size)))
+    return blob
+
+  def set_state(self, blob):
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    _check(self.lib.blcd_set_state(self._h, _ptr(blob), blob.size))
+
+  def faults(self):
+    f = np.zeros(self.n, np.int32)
+    _check(self.lib.blcd_get_faults(self._h, _ptr(f)))
+    return f
+
+  def sync(self):
+    _check(self.lib.blcd_sync(self._h))
+
+  def stream(self):
+    return self.lib.blcd_stream(self._h)
+
+  def last_kernel_ms(self):
+    ms, n = C.c_float(0), C.c_int32(0)
+    _check(self.lib.blcd_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+  # parity hooks
+  def debug_world_step(self, n=1):
+    _check(self.lib.blcd_debug_world_step(self._h, int(n)))
+
+  def debug_set_motor_speeds(self, actions):
+    actions = np.ascontiguousarray(actions, dtype=np.float32)
+    _check(self.lib.blcd_debug_set_motor_speeds(self._h, _ptr(actions)))
+
+  def debug_dump(self):
+    b = np.zeros((self.n, self.nb, BODY_F), np.float32)
+    j = np.zeros((self.n, max(self.nj, 1), JOINT_F), np.float32)
+    p = np.zeros((self.n, max(self.n_pairs, 1), PAIR_F), np.float32)
+    _check(self.lib.blcd_debug_dump(self._h, _ptr(b), _ptr(j), _ptr(p)))
+    return b, j[:, :self.nj], p[:, :self.n_pairs]

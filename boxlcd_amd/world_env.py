@@ -1,0 +1,370 @@
+"""`WorldEnv` (single gym-style env) and `BatchedWorldEnv` (N envs, AsyncVectorEnv call shapes) over the HIP C-ABI.
+
+Mirrors the reference's `boxLCD/world_env.py` API: constructor + config (:47-61), obs/action specification
+(:69-142), properties (:144-166), `seed` (:168-170), `reset(full_state=None, proprio=None)` (:306-385),
+`step(action)` (:431-458), `lcd_render` (:460-512), `render` (:514-535), `close` (:185-188).
+The physics (`b2World.Step`), `_get_obs` and the PIL raster run on the GPU in libboxlcd_hip.so; this file keeps the
+host-side glue the reference has in Python: the float64 numpy sampling of initial poses and the
+normalised-state -> pose conversion of `reset(full_state=)`.
+
+There is no CPU fallback: constructing an env only needs the host tables, but `reset/step/render` raise
+`RuntimeError` if the HIP library or a GPU is missing.
+"""
+import hashlib
+import os
+import struct
+import numpy as np
+from . import utils
+from . import spaces as _spaces
+from .scene import compile_scene, fill_robots, KIND_OBJECT, KIND_ROOT, KIND_LINK
+
+A = utils.A
+
+
+# --- gym 0.17.3 `gym.utils.seeding.np_random` restated (reference world_env.py:169 uses it) -----------------------
+def _bigint_from_bytes(b):
+  sizeof_int = 4
+  padding = sizeof_int - len(b) % sizeof_int
+  b += b'\0' * padding
+  int_count = int(len(b) / sizeof_int)
+  unpacked = struct.unpack('{}I'.format(int_count), b)
+  accum = 0
+  for i, val in enumerate(unpacked):
+    accum += 2**(sizeof_int * 8 * i) * val
+  return accum
+
+
+def np_random(seed=None):
+  if seed is not None and not (isinstance(seed, (int, np.integer)) and 0 <= seed):
+    raise ValueError('Seed must be a non-negative integer or omitted, not {}'.format(seed))
+  if seed is None:
+    seed = _bigint_from_bytes(os.urandom(8))
+  seed = int(seed) % 2**(8 * 8)
+  h = hashlib.sha512(str(seed).encode('utf8')).digest()
+  big = _bigint_from_bytes(h[:8])
+  ints = []
+  if big == 0:
+    ints = [0]
+  while big > 0:
+    big, mod = divmod(big, 2**32)
+    ints.append(mod)
+  rng = np.random.RandomState()
+  rng.seed(ints)
+  return rng, seed
+
+
+def _f32(x):
+  return np.asarray(x, dtype=np.float64).astype(np.float32)
+
+
+class _EnvSpec:
+  """Everything about an env class+config that does not need the GPU (shared by WorldEnv and BatchedWorldEnv)."""
+
+  ENV_DG = utils.AttrDict()
+  ENV_DG.base_dim = 5
+  ENV_DG.lcd_base = 16
+  ENV_DG.wh_ratio = 2.0
+  ENV_DG.ep_len = 100
+  ENV_DG.angular_offset = 0
+  ENV_DG.root_offset = 0
+  ENV_DG.compact_obs = 0
+  ENV_DG.use_speed = 1
+  ENV_DG.all_corners = 0
+  ENV_DG.walls = 1
+  ENV_DG.debug = 0
+  ENV_DG.fps = 10
+
+  def _init_spec(self, world_def, G, raster_variant=None):
+    self.G = utils.AttrDict(self.ENV_DG)
+    if not isinstance(G, dict):
+      G = G.__dict__
+    for key in G:
+      self.G[key] = G[key]
+    for key, want in (('walls', 1), ('use_speed', 1), ('all_corners', 0), ('root_offset', 0), ('angular_offset', 0), ('compact_obs', 0)):
+      if self.G[key] != want:
+        # the reference's non-default branches are broken; the defaults are the contract
+        raise NotImplementedError(f'G.{key}={self.G[key]} is outside the supported contract (default {want})')
+    if raster_variant is None:
+      raster_variant = int(os.environ.get('BOXLCD_RASTER_VARIANT', '0'))
+    self.raster_variant = raster_variant
+    self.world_def = fill_robots(world_def, self.G)
+    self.scene = compile_scene(self.world_def, self.G, self.WIDTH, self.HEIGHT, raster_variant)
+    self.obs_info = self.scene.obs_info
+    self.act_info = self.scene.act_info
+    self.obs_size = len(self.obs_info)
+    self.obs_keys = list(self.obs_info.keys())
+    self.pobs_keys = utils.nfiltlist(self.obs_keys, 'object')
+    self.pobs_size = len(self.pobs_keys)
+    self.pobs_idxs = [self.obs_keys.index(x) for x in self.pobs_keys]
+    sp = {}
+    sp['full_state'] = _spaces.Box(-1, +1, (self.obs_size,), dtype=np.float32)
+    sp['proprio'] = _spaces.Box(-1, +1, (self.pobs_size if self.pobs_size else 1,), dtype=np.float32)
+    sp['lcd'] = _spaces.Box(0, 1, (self.G.lcd_base, int(self.G.lcd_base * self.G.wh_ratio)), dtype=np.bool_)
+    self.observation_space = _spaces.Dict(sp)
+    self.act_size = len(self.act_info)
+    self.act_keys = list(self.act_info.keys())
+    self.action_space = _spaces.Box(-1, +1, (self.act_size,), dtype=np.float32)
+
+  @property
+  def WIDTH(self):
+    return int(self.G.wh_ratio * self.G.base_dim)
+
+  @property
+  def HEIGHT(self):
+    return self.G.base_dim
+
+  @property
+  def VIEWPORT_H(self):
+    return 30 * self.HEIGHT
+
+  @property
+  def VIEWPORT_W(self):
+    return 30 * self.WIDTH
+
+  @property
+  def FPS(self):
+    return self.G.fps
+
+  @property
+  def SCALE(self):
+    from .world_defs import SCALE
+    return SCALE
+
+  # ---- initial-state sampling: reference world_env.py:172-175 (_sample) and :197-304 (_reset_bodies) ------------
+  def _sample_poses(self, uniform, n, randint=None):
+    """Vectorised over n envs.  `uniform(lo, hi)` -> float64 [n] draws IN THE REFERENCE'S ORDER; returns
+    (poses float32 [n, nb, 3], shape_sel int32 [n, nb])."""
+    nb = len(self.scene.bodies)
+    poses = np.zeros((n, nb, 3), np.float32)
+    sel = np.zeros((n, nb), np.int32)
+    W, H = self.WIDTH, self.HEIGHT
+    info = self.obs_info
+
+    def S(key, lr=-1.0, ur=None):
+      if ur is None:
+        ur = -lr
+      return utils.mapto(uniform(lr, ur), info[key])
+
+    bodies = self.scene.bodies
+    pos32 = {}
+    for robot in self.world_def.robots:
+      name = robot.name + ':root'
+      rangex = 1 - (2 * robot.bound / W)
+      rangey = 1 - (2 * robot.bound / H)
+      rx = S(name + ':x:p', -rangex, rangex)
+      ry = S(name + ':y:p', -rangey, -rangey)
+      s_ = S(name + ':sin')
+      c_ = S(name + ':cos')
+      root_angle = np.arctan2(s_, c_)
+      if not robot.rand_angle:
+        root_angle = np.zeros(n)
+      root = bodies[self.scene.body_index[name]]
+      pos32[name] = np.stack([_f32(rx), _f32(ry)], -1)          # b2Vec2: float32 at the SWIG boundary
+      poses[:, root.index, :2] = pos32[name]
+      poses[:, root.index, 2] = _f32(root_angle)
+      parent_angles = {name: root_angle}
+      for jname, joint in robot.joints.items():
+        lname = robot.name + ':' + jname
+        pname = robot.name + ':' + joint.parent
+        mangle = root_angle + joint.angle
+        mangle = np.arctan2(np.sin(mangle), np.cos(mangle))
+        parent_angles[lname] = mangle
+        pangle = parent_angles[pname]
+        ax, ay = joint.anchorA
+        aa = np.stack([np.cos(pangle) * ax + -np.sin(pangle) * ay, np.sin(pangle) * ax + np.cos(pangle) * ay], -1)
+        bx, by = joint.anchorB
+        ab = np.stack([np.cos(mangle) * bx + -np.sin(mangle) * by, np.sin(mangle) * bx + np.cos(mangle) * by], -1)
+        # `b2Vec2 + ndarray - ndarray` runs in pybox2d's float32 b2Vec2 arithmetic (world_env.py:250) [upstream]
+        p = (pos32[pname] + _f32(aa)).astype(np.float32) - _f32(ab)
+        pos32[lname] = p.astype(np.float32)
+        link = bodies[self.scene.body_index[lname]]
+        poses[:, link.index, :2] = pos32[lname]
+        poses[:, link.index, 2] = _f32(mangle)
+    for obj in self.world_def.objects:
+      ob = bodies[self.scene.body_index[obj.name]]
+      if obj.shape == 'random':
+        sel[:, ob.index] = randint(2, n) if randint is not None else np.random.randint(2, size=n)
+      rangex = 1 - (2 * obj.size / W)
+      rangey = 1 - (2 * obj.size / H)
+      x = S(obj.name + ':x:p', -rangex, rangex)
+      if len(self.world_def.robots) == 0:
+        y = S(obj.name + ':y:p', -rangey, rangey)
+      else:
+        y = S(obj.name + ':y:p', -rangey, -0.25)
+      if obj.rand_angle:
+        s_ = S(obj.name + ':sin')
+        c_ = S(obj.name + ':cos')
+        angle = np.arctan2(s_, c_)
+      else:
+        angle = np.zeros(n)
+      poses[:, ob.index, 0] = _f32(x)
+      poses[:, ob.index, 1] = _f32(y)
+      poses[:, ob.index, 2] = _f32(angle)
+    return poses, sel
+
+  # ---- normalised full_state -> body poses: reference world_env.py:323-380 ---------------------------------
+  def _state_to_poses(self, full_state):
+    """full_state float64 [n, obs] -> (poses float32 [n, nb, 3]); every body is overwritten (objects, roots, links)."""
+    fs = utils.NamedArray(np.asarray(full_state, dtype=np.float64), self.obs_info)
+    n = fs.arr.shape[0]
+    nb = len(self.scene.bodies)
+    poses = np.zeros((n, nb, 3), np.float32)
+    for b in self.scene.bodies:
+      name = b.name
+      xy = fs[f'{name}:x:p', f'{name}:y:p']
+      ang = np.arctan2(fs[name + ':sin'], fs[name + ':cos'])
+      poses[:, b.index, :2] = _f32(xy)
+      poses[:, b.index, 2] = _f32(ang)
+    return poses
+
+
+class WorldEnv(_EnvSpec):
+  """One environment with the reference's gym-style API, backed by a 1-env GPU handle."""
+  metadata = {'render.modes': ['human', 'rgb_array']}
+
+  def __init__(self, world_def, G={}, device=0, raster_variant=None):
+    self._init_spec(world_def, G, raster_variant)
+    self._device = device
+    self._h = None
+    self.viewer = None
+    self.scroll = 0.0
+    self.ep_t = 0
+    self.seed()
+
+  def seed(self, seed=None):
+    self.np_random, seed = np_random(seed)
+    return [seed]
+
+  def _handle(self):
+    if self._h is None:
+      from ._lib import Handle
+      self._h = Handle(self.scene.desc, 1, self._device)
+    return self._h
+
+  def close(self):
+    if self._h is not None:
+      self._h.close()
+      self._h = None
+
+  def reset(self, full_state=None, proprio=None):
+    h = self._handle()
+    self.ep_t = 0
+    poses, sel = self._sample_poses(lambda lo, hi: np.array([self.np_random.uniform(lo, hi)]), 1)
+    h.reset(None, poses, sel)
+    if proprio is not None:
+      pshape = self.observation_space.spaces['proprio'].shape
+      assert np.shape(proprio)[-1] == pshape[-1], f'invalid shape for proprio {np.shape(proprio)} {pshape}'
+      full_state = np.zeros(self.observation_space.spaces['full_state'].shape)
+      full_state[self.pobs_idxs] = proprio
+    if full_state is not None:
+      fs = np.array(full_state).astype(np.float64)[None]
+      h.set_poses(None, self._state_to_poses(fs), None)
+    return self._get_obs()
+
+  def _get_obs(self):
+    fs, lcd = self._handle().get_obs(np.float64)
+    full_state = fs[0]
+    proprio = full_state[self.pobs_idxs] if self.pobs_size != 0 else np.zeros(1)
+    return {'full_state': full_state, 'proprio': proprio, 'lcd': lcd[0].astype(bool)}
+
+  def step(self, action):
+    self.ep_t += 1
+    a = np.asarray(action, dtype=np.float32).reshape(1, self.act_size)
+    self._handle().step(a, 1)
+    reward = 0.0
+    done = self.ep_t >= self.G.ep_len
+    info = {'timeout': done}
+    return self._get_obs(), reward, done, info
+
+  def lcd_render(self, width=None, height=None, lcd_mode='1'):
+    lcd_mode = lcd_mode.upper()
+    assert lcd_mode in ['1', 'RGB'], 'lcd_mode must be in one of these PIL supported modes'
+    dw, dh = int(self.G.lcd_base * self.G.wh_ratio), self.G.lcd_base
+    if (width is not None or height is not None) and (width, height) != (dw, dh) or lcd_mode != '1':
+      raise NotImplementedError('only the native binary LCD is rendered on device (display-only modes are out of scope)')
+    _, lcd = self._handle().get_obs(None)
+    return lcd[0].astype(bool)
+
+  def render(self, mode='rgb_array', lcd_mode='1', return_pyglet_view=False):
+    if mode != 'rgb_array':
+      raise NotImplementedError("mode='human' (pyglet viewer) is out of scope; use mode='rgb_array'")
+    return self.lcd_render(lcd_mode=lcd_mode)
+
+
+class BatchedWorldEnv(_EnvSpec):
+  """N independent envs of one class on one GPU, with the call shapes of the reference's vector env
+  (research/wrappers/async_vector_env.py: reset(idxs, **kwargs) :131-189, step(actions) :191-242) — one kernel launch
+  per step instead of one pipe round-trip per env."""
+
+  def __init__(self, env_cls, num_envs, G={}, device=0, seed=0, raster_variant=None):
+    if isinstance(env_cls, str):
+      from . import envs as _envs
+      env_cls = getattr(_envs, env_cls)
+    proto = env_cls(G, raster_variant=raster_variant)
+    self.ENV_DG = proto.ENV_DG
+    self._init_spec(proto.world_def, proto.G, proto.raster_variant)
+    self.env_cls = env_cls
+    self.num_envs = int(num_envs)
+    self.single_observation_space = self.observation_space
+    self.single_action_space = self.action_space
+    self._device = device
+    self._h = None
+    self.seed(seed)
+    self.ep_t = np.zeros(self.num_envs, np.int64)
+
+  def seed(self, seed=0):
+    self._rng = np.random.Generator(np.random.Philox(key=int(seed)))
+    self._act_rng = np.random.Generator(np.random.Philox(key=int(seed) + 1))
+    return [seed]
+
+  def _handle(self):
+    if self._h is None:
+      from ._lib import Handle
+      self._h = Handle(self.scene.desc, self.num_envs, self._device)
+    return self._h
+
+  def close(self):
+    if self._h is not None:
+      self._h.close()
+      self._h = None
+
+  def sample_initial(self, n):
+    """(poses, shape_sel) for n envs; float64 numpy arithmetic as in the reference, vectorised (Philox stream)."""
+    return self._sample_poses(lambda lo, hi: self._rng.uniform(lo, hi, n), n, randint=lambda k, m: self._rng.integers(0, k, m))
+
+  def sample_actions(self, T=None):
+    shape = (self.num_envs, self.act_size) if T is None else (T, self.num_envs, self.act_size)
+    return self._act_rng.uniform(-1, 1, shape).astype(np.float32)
+
+  def reset(self, idxs=None, full_state=None, proprio=None):
+    h = self._handle()
+    idxs = np.arange(self.num_envs, dtype=np.int32) if idxs is None else np.asarray(idxs, dtype=np.int32)
+    n = len(idxs)
+    poses, sel = self.sample_initial(n)
+    h.reset(idxs, poses, sel)
+    self.ep_t[idxs] = 0
+    if proprio is not None:
+      fs = np.zeros((n, self.obs_size))
+      fs[:, self.pobs_idxs] = np.asarray(proprio, dtype=np.float64)
+      full_state = fs
+    if full_state is not None:
+      h.set_poses(idxs, self._state_to_poses(np.asarray(full_state, dtype=np.float64)), None)
+    return self._obs()
+
+  def _obs(self):
+    fs, lcd = self._handle().get_obs(np.float32)
+    proprio = fs[:, self.pobs_idxs] if self.pobs_size != 0 else np.zeros((self.num_envs, 1), np.float32)
+    return {'full_state': fs, 'proprio': proprio, 'lcd': lcd.astype(bool)}
+
+  def step(self, actions):
+    a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_size))
+    self._handle().step(a, 1)
+    self.ep_t += 1
+    done = self.ep_t >= self.G.ep_len
+    infos = [{'timeout': bool(d)} for d in done]
+    return self._obs(), np.zeros(self.num_envs, np.float64), done, infos
+
+  def render_states(self, full_state):
+    """state -> LCD for M normalised states (the `env.reset(proprio=s)['lcd']` use), without touching env state."""
+    fs = np.asarray(full_state, dtype=np.float64)
+    return self._handle().render_poses(self._state_to_poses(fs), None).astype(bool)

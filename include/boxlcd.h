@@ -1,0 +1,172 @@
+/* boxlcd.h — C ABI of the MI355X-native batched boxLCD hot path (libboxlcd_hip.so).
+ *
+ * The reference (matwilso/boxLCD) has no FFI layer: its hot path is Python calling two un-vendored native
+ * libraries through their Python bindings.  Each entry point below therefore cites the reference *call site*
+ * it replaces (paths relative to the reference root); INTEGRATION.md shows the ctypes stub a boxLCD maintainer
+ * would add.
+ *
+ * Conventions: every function returns 0 on success and a negative blcd_status on failure (message via
+ * blcd_last_error(), thread-local).  The caller owns every buffer.  Buffers marked "host|device" may be plain
+ * host memory or HIP device memory on the handle's device (detected with hipPointerGetAttributes); device buffers
+ * are used in place (zero copy) on the handle's stream.  A handle is bound to one device and one HIP stream and is
+ * not thread-safe; different handles may be driven from different threads.  No exceptions cross the ABI.
+ * There is NO CPU fallback: blcd_create fails if no HIP device is usable.
+ */
+#ifndef BOXLCD_H
+#define BOXLCD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLCD_VERSION 100 /* 0.1.0 */
+
+#define BLCD_MAX_POLY_VERTS 8
+#define BLCD_MAX_BODIES 20
+#define BLCD_MAX_JOINTS 20
+#define BLCD_MAX_SHAPES 24
+#define BLCD_MAX_OBS 96
+
+typedef enum blcd_status {
+  BLCD_OK = 0,
+  BLCD_ERR_INVALID = -1,     /* bad argument / scene outside supported limits */
+  BLCD_ERR_NO_DEVICE = -2,   /* no usable HIP device (there is no CPU path) */
+  BLCD_ERR_HIP = -3,         /* a HIP runtime call failed */
+  BLCD_ERR_UNSUPPORTED = -4, /* scene needs a feature this build lacks */
+  BLCD_ERR_ENV_FAULT = -5    /* a per-env guard tripped on device (NaN state, ellipse outside LUT, pair overflow) */
+} blcd_status;
+
+/* ---- scene description: the data form of WorldEnv.__init__ + _reset_bodies (boxLCD/world_env.py:47-142,197-304),
+ *      world_defs.py:11-59 and envs.py:17-137.  Filled by boxlcd_amd/scene.py. ---- */
+typedef struct blcd_shape_def {
+  int32_t type;    /* 0 circleShape(radius), 1 polygonShape(...)  (world_env.py:273, world_defs.py:82-83,103-108) */
+  int32_t n_verts; /* polygonShape(vertices=...): count, goes through the b2PolygonShape::Set hull */
+  float radius;
+  int32_t is_box;  /* polygonShape(box=(hx,hy)): verts[0] = (hx, hy) */
+  float verts[BLCD_MAX_POLY_VERTS][2];
+} blcd_shape_def;
+
+typedef struct blcd_body_def {
+  int32_t n_choices; /* 2 for Object(shape='random') (world_env.py:273-274), else 1 */
+  int32_t shape[2];
+  float density, friction, restitution;
+  uint32_t category_bits, mask_bits;
+  float linear_damping, angular_damping;
+  int32_t kind; /* 0 object, 1 robot root, 2 robot link */
+  int32_t _pad;
+} blcd_body_def;
+
+typedef struct blcd_joint_def { /* revoluteJointDef(...) at world_env.py:255-266 */
+  int32_t body_a, body_b;
+  float anchor_a[2], anchor_b[2];
+  int32_t enable_limit;
+  float lower, upper;
+  float max_motor_torque;
+  float speed;          /* Joint.speed, the action scale at world_env.py:441 */
+  int32_t action_index; /* -1: joint is not actuated (world_env.py:438) */
+} blcd_joint_def;
+
+/* one entry per sorted observation key (world_env.py:120-122).
+ * kind: 0 x:p  1 y:p  2 cos(body.angle)  3 sin(body.angle)  4 cos(transform.angle)  5 sin(transform.angle) */
+typedef struct blcd_obs_def {
+  int32_t kind, body;
+  float lo, hi;
+} blcd_obs_def;
+
+typedef struct blcd_scene_desc {
+  int32_t n_bodies, n_joints, n_shapes, n_obs, n_act;
+  int32_t lcd_w, lcd_h;   /* int(lcd_base*wh_ratio), lcd_base (world_env.py:467-469) */
+  int32_t raster_variant; /* 0 legacy Pillow scan rule, 1 Pillow >= 12 corner joining */
+  float world_w, world_h; /* WIDTH = int(wh_ratio*base_dim), HEIGHT (world_env.py:144-150) */
+  float gravity[2];
+  float dt;               /* float32(1/(fps*3)) (world_env.py:448) */
+  int32_t substeps, vel_iters, pos_iters; /* 3, 180, 60 */
+  blcd_shape_def shapes[BLCD_MAX_SHAPES];
+  blcd_body_def bodies[BLCD_MAX_BODIES];
+  blcd_joint_def joints[BLCD_MAX_JOINTS];
+  blcd_obs_def obs[BLCD_MAX_OBS];
+} blcd_scene_desc;
+
+typedef struct blcd_handle_s* blcd_handle;
+
+/* library */
+int blcd_version(void);
+const char* blcd_last_error(void);
+int blcd_device_count(void);
+
+/* Replaces N x `envs.<Name>(G)` construction + `Box2D.b2World(gravity=...)` (world_env.py:47-67; the vector form
+ * research/wrappers/async_vector_env.py:98-109 forks one process per env instead). */
+int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, blcd_handle* out);
+int blcd_destroy(blcd_handle h);
+int blcd_num_envs(blcd_handle h);
+
+/* Static contact-pair slots (proxy ids: 0..3 = walls bottom,left,right,top; 4+i = body i) in (A,B)-sorted order:
+ * the pairs b2ContactManager::AddPair can ever accept for this scene. */
+int blcd_num_pairs(blcd_handle h);
+int blcd_pair_table(blcd_handle h, int32_t* pairs /* host [n_pairs][2] */);
+
+/* Replaces WorldEnv.reset()'s world construction (world_env.py:306-317 + _reset_bodies :197-304) for the envs in
+ * `idxs` (NULL = all, then n must equal n_envs).  poses = position/angle handed to CreateDynamicBody for every body,
+ * sampled on the host by boxlcd_amd/world_env.py exactly as the reference samples them (float64 numpy).
+ * idxs host; poses host|device float32 [n][n_bodies][3]; shape_sel host|device int32 [n][n_bodies] or NULL. */
+int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const int32_t* shape_sel);
+
+/* Replaces the `body.position = ...; body.angle = ...` overwrite of reset(full_state=/proprio=) (world_env.py:319-380):
+ * b2Body::SetTransform semantics (velocities untouched, broad-phase proxy refreshed).  mask host uint8 [n_bodies] or NULL. */
+int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const uint8_t* mask);
+
+/* Replaces WorldEnv.step(action) (world_env.py:431-458) for all envs, n_steps times with the same actions:
+ * action -> motorSpeed (utils.py:117 + world_env.py:441), then `substeps` x b2World.Step(dt, vel_iters, pos_iters).
+ * actions host|device float32 [n_envs][n_act] (NULL = zeros). */
+int blcd_step(blcd_handle h, const float* actions, int32_t n_steps);
+
+/* Fused rollout, replaces the inner loop of research/data.py:56-61 (`for j in range(ep_len): venv.step(act)`):
+ * T env-steps with per-step actions [T][n_envs][n_act]; per-step outputs (any may be NULL):
+ * lcd_out uint8 [T][n_envs][lcd_h][lcd_w], obs_out float32 [T][n_envs][n_obs].  All host|device. */
+int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out);
+
+/* Replaces WorldEnv._get_obs() (world_env.py:387-429) incl. lcd_render() (:460-512).
+ * full_state: normalised [n_envs][n_obs], dtype 0 = float32 (vector-env layout, async_vector_env.py:374-378),
+ * 1 = float64 (single-env layout, world_env.py:388,427); lcd uint8 [n_envs][lcd_h][lcd_w], 1 = background, 0 = body.
+ * Either pointer may be NULL.  host|device. */
+int blcd_get_obs(blcd_handle h, void* full_state, int32_t dtype, uint8_t* lcd);
+
+/* Replaces the `env.reset(proprio=s)['lcd']` state->LCD use (research/nets/autoencoders/_base.py:69,76):
+ * renders m pose sets without touching env state.  poses float32 [m][n_bodies][3] (x, y, angle of each body's
+ * transform), shape_sel int32 [m][n_bodies] or NULL; lcd uint8 [m][lcd_h][lcd_w].  host|device. */
+int blcd_render_poses(blcd_handle h, const float* poses, const int32_t* shape_sel, int32_t m, uint8_t* lcd);
+
+/* Body poses for host-side consumers: float32 [n_envs][n_bodies][4] = transform.position.x, .y, body.angle, awake. */
+int blcd_get_poses(blcd_handle h, float* poses);
+
+/* Full snapshot (positions, velocities, impulses, contacts, sleep state) — the reference never checkpoints env state
+ * (SURVEY.md §5); needed for mid-rollout parity tests and exact resume.  *size in/out (query with blob == NULL). */
+int blcd_get_state(blcd_handle h, void* blob, size_t* size);
+int blcd_set_state(blcd_handle h, const void* blob, size_t size);
+
+/* Per-env fault flags raised on device since the last reset (0 = healthy): int32 [n_envs], host. */
+int blcd_get_faults(blcd_handle h, int32_t* flags);
+
+/* Blocks until the handle's stream is idle; blcd_stream returns the hipStream_t so torch can order work against it. */
+int blcd_sync(blcd_handle h);
+void* blcd_stream(blcd_handle h);
+
+/* Kernel-only timing of the last blcd_step/blcd_rollout launch sequence, measured with hipEvents on the handle's
+ * stream (ms); used by bench.py's roofline block. */
+int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches);
+
+/* ---- parity-test hooks (sub-step granularity + canonical dump; same layout as oracle/b2o_api.h's b2o_dump) ---- */
+#define BLCD_BODY_STATE_FLOATS 12 /* cx cy a vx vy w sleepTime awake fat.lo.x fat.lo.y fat.hi.x fat.hi.y */
+#define BLCD_JOINT_STATE_FLOATS 5 /* impulse.x impulse.y impulse.z motorImpulse limitState */
+#define BLCD_PAIR_STATE_FLOATS 18 /* exists touching type pointCount ln.xy lp.xy {p.xy ni ti}x2 id0 id1 */
+int blcd_debug_world_step(blcd_handle h, int32_t n_world_steps);           /* n x b2World::Step only */
+int blcd_debug_set_motor_speeds(blcd_handle h, const float* actions);       /* the action half of step() only */
+int blcd_debug_dump(blcd_handle h, float* bodies, float* joints, float* pairs); /* host [n_envs][..][FLOATS] */
+int blcd_debug_sincos(const float* x, int64_t n, float* s, float* c, int32_t device); /* device sincosf on host arrays */
+int blcd_debug_mass_data(const blcd_scene_desc* scene, int32_t shape, float density, float* out16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOXLCD_H */

@@ -1,0 +1,132 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under boxlcd_amd/ may include, link or call this.
+//
+// CPU restatement of the Pillow calls made by boxLCD's `WorldEnv.lcd_render` in mode '1'
+// (reference: boxLCD/world_env.py:460-512: Image.new / draw.rectangle(bg=1) / draw.ellipse / draw.polygon /
+// FLIP_TOP_BOTTOM).  Pillow (`Pillow==9.0.1`, requirements.txt:19) is un-vendored; the scan-conversion rules are
+// the behavioural spec of SURVEY.md App. C (probed against Pillow 12.2.0):
+//   variant 1 "modern"  = Pillow 12.2.0 (with sub-pixel corner joining)      -> pinned by tests/golden/pillow_*.npz
+//   variant 0 "legacy"  = the same scan rule without corner joining (what the reference's published GIF frames show)
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <algorithm>
+#include "b2o_ellipse_lut.h"
+
+namespace b2o {
+
+struct Canvas {
+  int W, H;
+  uint8_t* px;  // H*W, 1 = background, 0 = body; image coordinates (y down), not yet flipped
+};
+
+static inline void hline(Canvas& im, int x0, int y0, int x1) {
+  if (y0 >= 0 && y0 < im.H) {
+    if (x0 < 0) x0 = 0;
+    else if (x0 >= im.W) return;
+    if (x1 < 0) return;
+    else if (x1 >= im.W) x1 = im.W - 1;
+    if (x0 <= x1) std::memset(im.px + y0 * im.W + x0, 0, x1 - x0 + 1);
+  }
+}
+
+static inline int RoundUp(float f) { return (int)(f >= 0.0f ? floor(f + 0.5f) : -floor(fabs(f) + 0.5f)); }
+static inline int RoundDown(float f) { return (int)(f >= 0.0f ? ceil(f - 0.5f) : -ceil(fabs(f) - 0.5f)); }
+
+struct Edge {
+  int xmin, ymin, xmax, ymax;
+  int x0, y0;
+  float dx;
+};
+static inline void add_edge(Edge* e, int x0, int y0, int x1, int y1) {
+  if (x0 <= x1) e->xmin = x0, e->xmax = x1; else e->xmin = x1, e->xmax = x0;
+  if (y0 <= y1) e->ymin = y0, e->ymax = y1; else e->ymin = y1, e->ymax = y0;
+  if (y0 == y1) e->dx = 0.0f; else e->dx = ((float)(x1 - x0)) / (y1 - y0);
+  e->x0 = x0;
+  e->y0 = y0;
+}
+static inline float edge_x(const Edge* e, int y) { return (y - e->y0) * e->dx + e->x0; }
+
+// ImagingDrawPolygon(fill) on integer vertices
+static inline void draw_polygon(Canvas& im, const int* xy, int count, int variant) {
+  const int MAXE = 40;
+  if (count <= 0 || count + 1 > MAXE) return;
+  Edge e[MAXE];
+  int n = 0;
+  for (int i = 0; i < count - 1; i++) add_edge(&e[n++], xy[i * 2], xy[i * 2 + 1], xy[i * 2 + 2], xy[i * 2 + 3]);
+  if (xy[(count - 1) * 2] != xy[0] || xy[(count - 1) * 2 + 1] != xy[1])
+    add_edge(&e[n++], xy[(count - 1) * 2], xy[(count - 1) * 2 + 1], xy[0], xy[1]);
+  const Edge* table[MAXE];
+  int edge_count = 0;
+  int ymin = im.H - 1, ymax = 0;
+  for (int i = 0; i < n; i++) {
+    if (ymin > e[i].ymin) ymin = e[i].ymin;
+    if (ymax < e[i].ymax) ymax = e[i].ymax;
+    if (e[i].ymin == e[i].ymax) {
+      hline(im, e[i].xmin, e[i].ymin, e[i].xmax);
+      continue;
+    }
+    table[edge_count++] = &e[i];
+  }
+  if (ymin < 0) ymin = 0;
+  if (ymax > im.H) ymax = im.H;
+  float xx[2 * MAXE];
+  for (int y = ymin; y <= ymax; y++) {
+    int j = 0;
+    for (int i = 0; i < edge_count; i++) {
+      const Edge* cur = table[i];
+      if (y >= cur->ymin && y <= cur->ymax) {
+        xx[j++] = edge_x(cur, y);
+        if (y == cur->ymax && y < ymax) {
+          xx[j] = xx[j - 1];
+          j++;
+        } else if (variant == 1 && cur->dx != 0.0f && roundf(xx[j - 1]) == xx[j - 1]) {
+          for (int k = 0; k < i; k++) {
+            const Edge* oth = table[k];
+            if ((cur->dx > 0 && oth->dx <= 0) || (cur->dx < 0 && oth->dx >= 0)) continue;
+            if (!((y == cur->ymin && y == oth->ymin) || (y == cur->ymax && y == oth->ymax))) continue;
+            if (xx[j - 1] == edge_x(oth, y)) {
+              int off = (y == ymax) ? -1 : 1;
+              float a = edge_x(cur, y + off), b = edge_x(oth, y + off);
+              int v;
+              if (y == cur->ymax) v = cur->dx > 0 ? RoundUp(a > b ? a : b) + 1 : RoundUp(a < b ? a : b) - 1;
+              else v = cur->dx > 0 ? RoundUp(a < b ? a : b) - 1 : RoundUp(a > b ? a : b) + 1;
+              bool want_left = (y == cur->ymax) ? (cur->dx > 0) : (cur->dx < 0);
+              float corner_x = xx[j - 1];
+              if ((float)v == corner_x || (((float)v < corner_x) == want_left)) xx[j - 1] = (float)v;
+              break;
+            }
+          }
+        }
+      }
+    }
+    std::sort(xx, xx + j);
+    int x_pos = 0;
+    for (int i = 1; i < j; i += 2) {
+      int x_end = RoundDown(xx[i]);
+      if (x_end < x_pos) continue;
+      int x_start = RoundUp(xx[i - 1]);
+      if (x_pos > x_start) {
+        x_start = x_pos;
+        if (x_end < x_start) continue;
+      }
+      hline(im, x_start, y, x_end);
+      x_pos = x_end + 1;
+    }
+  }
+}
+
+// ImagingDrawEllipse(fill) on the truncated bbox: LUT dumped from Pillow (tools/gen_ellipse_lut.py)
+static inline bool draw_ellipse(Canvas& im, int x0, int y0, int x1, int y1) {
+  int a = x1 - x0, b = y1 - y0;
+  if (a < 0 || b < 0) return false;
+  if (a > KELLIPSELUT_AMAX || b > KELLIPSELUT_AMAX) return false;
+  for (int r = 0; r <= b; r++) {
+    int s = kEllipseLut_data[a][b][r][0], t = kEllipseLut_data[a][b][r][1];
+    if (s > t) continue;
+    hline(im, x0 + s, y0 + r, x0 + t);
+  }
+  return true;
+}
+
+}  // namespace b2o
