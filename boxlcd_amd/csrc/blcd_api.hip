@@ -1,0 +1,942 @@
+// blcd_api.hip — kernels and the C ABI (include/boxlcd.h) of libboxlcd_hip.so.  gfx950 only, no CPU fallback.
+//
+// Host side: scene lowering (hull/centroid/mass data/pair-slot table: b2PolygonShape::Set, ComputeMass,
+// b2Body::ResetMassData, the static half of b2ContactManager::AddPair), device-state ownership, staging of host
+// buffers, launches on the handle's HIP stream, hipEvent timing of the step launches.
+// Device side: one thread per environment (see blcd_world.h / blcd_raster.h).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/boxlcd.h"
+#include "blcd_raster.h"
+#include "blcd_world.h"
+
+using namespace blcd;
+
+// ---------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess) return fail(BLCD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kBlock = 64;  // one wave per workgroup: N/64 workgroups spread over 256 CUs
+
+template <int NB, int NJ, int NP>
+__global__ __launch_bounds__(kBlock) void step_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N,
+                                                      const float* __restrict__ actions, int nEnvSteps, int nWorldSteps,
+                                                      int setMotors) {
+  int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= N) return;
+  Env<NB, NJ, NP> env;
+  env.load(S, st, N, e);
+  if (nEnvSteps > 0) {
+    for (int t = 0; t < nEnvSteps; ++t) {
+      env.setMotorSpeeds(actions, N, e);
+      for (int k = 0; k < S->substeps; ++k) env.worldStep();
+    }
+  } else {
+    if (setMotors) env.setMotorSpeeds(actions, N, e);
+    for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
+  }
+  env.checkFault();
+  env.store(st, N, e);
+}
+
+// world construction for the listed envs: b2World::CreateBody + CreateFixture (proxy: tight AABB +- aabbExtension, buffered
+// as moved, e_newFixture), revolute joints with referenceAngle = bodyB.angle - bodyA.angle.
+__global__ void reset_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ idxs,
+                             int n, const float* __restrict__ poses, const int* __restrict__ shapeSel) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int e = idxs ? idxs[k] : k;
+  if (e < 0 || e >= N) return;
+  const int nb = S->nb, nj = S->nj, np = S->np;
+  float ang[BLCD_MAX_BODIES];
+  for (int i = 0; i < nb; ++i) {
+    const float* p = poses + ((size_t)k * nb + i) * 3;
+    int sel = shapeSel ? shapeSel[(size_t)k * nb + i] : 0;
+    if (sel < 0 || sel >= S->bodies[i].nChoices) sel = 0;
+    const DevVariant& var = S->bodies[i].var[sel];
+    Transform xf;
+    xf.p = V2(p[0], p[1]);
+    xf.q.Set(p[2]);
+    ang[i] = p[2];
+    Vec2 c = Mul(xf, var.localCenter);  // ResetMassData: sweep.c0 = sweep.c = b2Mul(xf, localCenter)
+    AABB aabb;
+    ShapeComputeAABB(&S->shapes[var.shape], &aabb, xf);
+    float* o = st + (size_t)(i * kBodyFields) * N + e;
+    o[0] = c.x;
+    o[(size_t)1 * N] = c.y;
+    o[(size_t)2 * N] = p[2];
+    o[(size_t)3 * N] = 0.0f;
+    o[(size_t)4 * N] = 0.0f;
+    o[(size_t)5 * N] = 0.0f;
+    o[(size_t)6 * N] = c.x;
+    o[(size_t)7 * N] = c.y;
+    o[(size_t)8 * N] = p[2];
+    o[(size_t)9 * N] = xf.p.x;
+    o[(size_t)10 * N] = xf.p.y;
+    o[(size_t)11 * N] = 0.0f;
+    o[(size_t)12 * N] = 1.0f;
+    o[(size_t)13 * N] = aabb.lo.x - kAabbExtension;
+    o[(size_t)14 * N] = aabb.lo.y - kAabbExtension;
+    o[(size_t)15 * N] = aabb.hi.x + kAabbExtension;
+    o[(size_t)16 * N] = aabb.hi.y + kAabbExtension;
+    o[(size_t)17 * N] = __int_as_float(sel);
+  }
+  float* pp = st + (size_t)(nb * kBodyFields) * N + e;
+  for (int s = 0; s < np * kPairFields; ++s) pp[(size_t)s * N] = 0.0f;
+  float* jp = pp + (size_t)(np * kPairFields) * N;
+  for (int j = 0; j < nj; ++j) {
+    float* o = jp + (size_t)(j * kJointFields) * N;
+    for (int f = 0; f < 6; ++f) o[(size_t)f * N] = 0.0f;
+    o[(size_t)6 * N] = ang[S->joints[j].bodyB] - ang[S->joints[j].bodyA];
+  }
+  float* wp = jp + (size_t)(nj * kJointFields) * N;
+  wp[0] = 0.0f;                                                   // m_inv_dt0
+  wp[(size_t)1 * N] = __uint_as_float(nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u));  // every proxy is in the move buffer
+  wp[(size_t)2 * N] = __uint_as_float((uint32_t)WF_NEWFIXTURE);
+  wp[(size_t)3 * N] = __int_as_float(0);
+  for (int k2 = 0; k2 < (np + 3) / 4; ++k2) wp[(size_t)(4 + k2) * N] = 0.0f;
+}
+
+// b2Body::SetTransform per masked body: position first, then angle (two calls, like `body.position=`; `body.angle=`),
+// each followed by proxy synchronisation with zero displacement; new contacts are looked for at the next step.
+template <int NB, int NJ, int NP>
+__global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ idxs,
+                                 int n, const float* __restrict__ poses, const uint8_t* __restrict__ mask) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int e = idxs ? idxs[k] : k;
+  if (e < 0 || e >= N) return;
+  Env<NB, NJ, NP> env;
+  env.load(S, st, N, e);
+  for (int i = 0; i < S->nb; ++i) {
+    if (mask && !mask[i]) continue;
+    const float* p = poses + ((size_t)k * S->nb + i) * 3;
+    for (int pass = 0; pass < 2; ++pass) {
+      float angle = pass == 0 ? env.a[i] : p[2];
+      Vec2 pos = pass == 0 ? V2(p[0], p[1]) : env.xfp[i];
+      env.q[i].Set(angle);
+      env.xfp[i] = pos;
+      Transform xf = env.xfOf(4 + i);
+      env.c[i] = Mul(xf, env.lc[i]);
+      env.a[i] = angle;
+      env.c0[i] = env.c[i];
+      env.a0[i] = angle;
+      env.synchronizeProxy(i, xf, xf);
+    }
+  }
+  // the reference's setters call FindNewContacts immediately; contacts are (A,B)-sorted here at the next step instead
+  env.wflags |= WF_NEWFIXTURE;
+  env.store(st, N, e);
+}
+
+template <int H, typename RowT, typename ObsT>
+__global__ __launch_bounds__(kBlock) void obs_kernel(const DevScene* __restrict__ S, const float* st, int N,
+                                                     ObsT* __restrict__ obs, uint8_t* __restrict__ lcd,
+                                                     float* stw) {
+  int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= N) return;
+  const int nb = S->nb;
+  if (obs) {
+    for (int i = 0; i < S->nobs; ++i) {
+      const DevObs od = S->obs[i];
+      const float* p = st + (size_t)(od.body * kBodyFields) * N + e;
+      double val;
+      if (od.kind == 0) val = (double)p[(size_t)9 * N];
+      else if (od.kind == 1) val = (double)p[(size_t)10 * N];
+      else {
+        float a = p[(size_t)2 * N];
+        if (od.kind >= 4) {  // transform.angle = atan2f(q.s, q.c)
+          Rot q;
+          q.Set(a);
+          a = atan2f(q.s, q.c);
+        }
+        val = (od.kind == 2 || od.kind == 4) ? cos((double)a) : sin((double)a);
+      }
+      double lo = (double)od.lo, hi = (double)od.hi;
+      obs[(size_t)e * S->nobs + i] = (ObsT)(((val - lo) / (hi - lo) * 2.0) + -1.0);
+    }
+  }
+  if (lcd) {
+    Raster<H, RowT> r;
+    r.clear(S->lcdW, S->rasterVariant);
+    bool ok = true;
+    for (int i = 0; i < nb; ++i) {
+      const float* p = st + (size_t)(i * kBodyFields) * N + e;
+      Transform xf;
+      xf.p = V2(p[(size_t)9 * N], p[(size_t)10 * N]);
+      xf.q.Set(p[(size_t)2 * N]);
+      int sel = __float_as_int(p[(size_t)17 * N]);
+      ok = r.drawBody(&S->shapes[S->bodies[i].var[sel].shape], xf, (double)S->worldW, (double)S->lcdW) && ok;
+    }
+    r.write(lcd + (size_t)e * H * S->lcdW);
+    if (!ok && stw) {
+      size_t off = (size_t)(nb * kBodyFields + S->np * kPairFields + S->nj * kJointFields + 2) * N + e;
+      stw[off] = __uint_as_float(__float_as_uint(stw[off]) | ((uint32_t)FAULT_ELLIPSE << 8));
+    }
+  }
+}
+
+template <int H, typename RowT>
+__global__ void render_poses_kernel(const DevScene* __restrict__ S, int m, const float* __restrict__ poses,
+                                    const int* __restrict__ shapeSel, uint8_t* __restrict__ lcd) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const int nb = S->nb;
+  Raster<H, RowT> r;
+  r.clear(S->lcdW, S->rasterVariant);
+  for (int i = 0; i < nb; ++i) {
+    const float* p = poses + ((size_t)k * nb + i) * 3;
+    Transform xf;
+    xf.p = V2(p[0], p[1]);
+    xf.q.Set(p[2]);
+    int sel = shapeSel ? shapeSel[(size_t)k * nb + i] : 0;
+    if (sel < 0 || sel >= S->bodies[i].nChoices) sel = 0;
+    r.drawBody(&S->shapes[S->bodies[i].var[sel].shape], xf, (double)S->worldW, (double)S->lcdW);
+  }
+  r.write(lcd + (size_t)k * H * S->lcdW);
+}
+
+__global__ void poses_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, float* __restrict__ out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  for (int i = 0; i < S->nb; ++i) {
+    const float* p = st + (size_t)(i * kBodyFields) * N + e;
+    float* o = out + ((size_t)e * S->nb + i) * 4;
+    o[0] = p[(size_t)9 * N];
+    o[1] = p[(size_t)10 * N];
+    o[2] = p[(size_t)2 * N];
+    o[3] = p[(size_t)12 * N];
+  }
+}
+
+__global__ void faults_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int* __restrict__ out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  size_t off = (size_t)(S->nb * kBodyFields + S->np * kPairFields + S->nj * kJointFields + 2) * N + e;
+  out[e] = (int)(__float_as_uint(st[off]) >> 8);
+}
+
+// canonical dump (same layout as the oracle's b2o_dump)
+__global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, float* __restrict__ bodies,
+                            float* __restrict__ joints, float* __restrict__ pairs) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int nb = S->nb, nj = S->nj, np = S->np;
+  const int bmap[12] = {0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16};
+  for (int i = 0; i < nb; ++i) {
+    const float* p = st + (size_t)(i * kBodyFields) * N + e;
+    float* o = bodies + ((size_t)e * nb + i) * BLCD_BODY_STATE_FLOATS;
+    for (int f = 0; f < 12; ++f) o[f] = p[(size_t)bmap[f] * N];
+  }
+  const float* pp = st + (size_t)(nb * kBodyFields) * N + e;
+  for (int s = 0; s < np; ++s) {
+    const float* p = pp + (size_t)(s * kPairFields) * N;
+    float* o = pairs + ((size_t)e * np + s) * BLCD_PAIR_STATE_FLOATS;
+    for (int f = 0; f < BLCD_PAIR_STATE_FLOATS; ++f) o[f] = 0.0f;
+    int fl = __float_as_int(p[0]);
+    if (!(fl & PF_EXISTS)) continue;
+    int tc = __float_as_int(p[(size_t)1 * N]);
+    int cnt = tc >> 8;
+    o[0] = 1.0f;
+    o[1] = (fl & PF_TOUCHING) ? 1.0f : 0.0f;
+    o[3] = (float)cnt;
+    if (cnt > 0) {
+      o[2] = (float)(tc & 0xff);
+      for (int f = 0; f < 4; ++f) o[4 + f] = p[(size_t)(2 + f) * N];
+      for (int k = 0; k < cnt; ++k) {
+        const float* r = p + (size_t)(6 + 5 * k) * N;
+        for (int f = 0; f < 4; ++f) o[8 + 4 * k + f] = r[(size_t)f * N];
+        uint32_t key = __float_as_uint(r[(size_t)4 * N]);
+        o[16 + k] = (float)((key & 0xff) + 16 * ((key >> 8) & 0xff) + 256 * ((key >> 16) & 0xff) + 512 * ((key >> 24) & 0xff));
+      }
+    }
+  }
+  const float* jp = pp + (size_t)(np * kPairFields) * N;
+  for (int j = 0; j < nj; ++j) {
+    const float* p = jp + (size_t)(j * kJointFields) * N;
+    float* o = joints + ((size_t)e * nj + j) * BLCD_JOINT_STATE_FLOATS;
+    o[0] = p[0];
+    o[1] = p[(size_t)1 * N];
+    o[2] = p[(size_t)2 * N];
+    o[3] = p[(size_t)3 * N];
+    o[4] = (float)__float_as_int(p[(size_t)4 * N]);
+  }
+}
+
+__global__ void sincos_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ s, float* __restrict__ c) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) blcd_sincosf(x[i], &s[i], &c[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host: scene lowering
+// ---------------------------------------------------------------------------------------------------------
+static Shape build_shape(const blcd_shape_def& d) {
+  Shape s;
+  std::memset(&s, 0, sizeof(s));
+  if (d.type == 0) {
+    ShapeSetCircle(&s, d.radius);
+  } else if (d.is_box) {
+    ShapeSetAsBox(&s, d.verts[0][0], d.verts[0][1]);
+  } else {
+    Vec2 vs[BLCD_MAX_POLY_VERTS];
+    int n = d.n_verts < BLCD_MAX_POLY_VERTS ? d.n_verts : BLCD_MAX_POLY_VERTS;
+    for (int i = 0; i < n; ++i) vs[i] = V2(d.verts[i][0], d.verts[i][1]);
+    ShapeSetPolygon(&s, vs, n);
+  }
+  return s;
+}
+
+// b2Body::ResetMassData for a single-fixture dynamic body
+static void mass_variant(const Shape& s, float density, DevVariant* v) {
+  float mass = 0.0f, I = 0.0f;
+  Vec2 localCenter = V2(0.0f, 0.0f);
+  if (density != 0.0f) {
+    MassData md;
+    ShapeComputeMass(&s, &md, density);
+    mass += md.mass;
+    localCenter += md.mass * md.center;
+    I += md.I;
+  }
+  float invMass, invI;
+  if (mass > 0.0f) {
+    invMass = 1.0f / mass;
+    localCenter *= invMass;
+  } else {
+    mass = 1.0f;
+    invMass = 1.0f;
+  }
+  if (I > 0.0f) {
+    I -= mass * Dot(localCenter, localCenter);
+    invI = 1.0f / I;
+  } else {
+    I = 0.0f;
+    invI = 0.0f;
+  }
+  v->mass = mass;
+  v->invMass = invMass;
+  v->I = I;
+  v->invI = invI;
+  v->localCenter = localCenter;
+}
+
+static int lower_scene(const blcd_scene_desc& d, DevScene* S) {
+  if (d.n_bodies < 1 || d.n_bodies > BLCD_MAX_BODIES) return fail(BLCD_ERR_INVALID, "n_bodies out of range");
+  if (d.n_joints < 0 || d.n_joints > BLCD_MAX_JOINTS) return fail(BLCD_ERR_INVALID, "n_joints out of range");
+  if (d.n_shapes < 1 || d.n_shapes > BLCD_MAX_SHAPES) return fail(BLCD_ERR_INVALID, "n_shapes out of range");
+  if (d.n_obs < 0 || d.n_obs > BLCD_MAX_OBS) return fail(BLCD_ERR_INVALID, "n_obs out of range");
+  if (!((d.lcd_h == 16 && d.lcd_w <= 32) || (d.lcd_h == 32 && d.lcd_w <= 64)) || d.lcd_w % 8 != 0)
+    return fail(BLCD_ERR_UNSUPPORTED, "LCD size must be 16x{16,24,32} or 32x{32,48,64}");
+  std::memset(S, 0, sizeof(*S));
+  S->nb = d.n_bodies;
+  S->nj = d.n_joints;
+  S->nobs = d.n_obs;
+  S->nact = d.n_act;
+  S->lcdW = d.lcd_w;
+  S->lcdH = d.lcd_h;
+  S->rasterVariant = d.raster_variant;
+  S->worldW = d.world_w;
+  S->worldH = d.world_h;
+  S->gravity = V2(d.gravity[0], d.gravity[1]);
+  S->dt = d.dt;
+  S->substeps = d.substeps;
+  S->velIters = d.vel_iters;
+  S->posIters = d.pos_iters;
+  S->nShapes = d.n_shapes;
+  // walls: boxLCD/world_env.py:311-314 — bottom, left, right, top
+  float W = d.world_w, H = d.world_h;
+  Vec2 ev[4][2] = {{V2(0, 0), V2(W, 0)}, {V2(0, 0), V2(0, H)}, {V2(W, 0), V2(W, H)}, {V2(0, H), V2(W, H)}};
+  Transform ident;
+  ident.p = V2(0.0f, 0.0f);
+  ident.q.Set(0.0f);
+  for (int i = 0; i < 4; ++i) {
+    ShapeSetEdge(&S->wallShape[i], ev[i][0], ev[i][1]);
+    AABB aabb;
+    ShapeComputeAABB(&S->wallShape[i], &aabb, ident);
+    S->wallFat[i].lo = aabb.lo - V2(kAabbExtension, kAabbExtension);
+    S->wallFat[i].hi = aabb.hi + V2(kAabbExtension, kAabbExtension);
+  }
+  for (int i = 0; i < d.n_shapes; ++i) S->shapes[i] = build_shape(d.shapes[i]);
+  for (int i = 0; i < d.n_bodies; ++i) {
+    const blcd_body_def& bd = d.bodies[i];
+    DevBody& B = S->bodies[i];
+    if (bd.n_choices < 1 || bd.n_choices > 2) return fail(BLCD_ERR_INVALID, "body n_choices must be 1 or 2");
+    B.nChoices = bd.n_choices;
+    for (int k = 0; k < bd.n_choices; ++k) {
+      if (bd.shape[k] < 0 || bd.shape[k] >= d.n_shapes) return fail(BLCD_ERR_INVALID, "body shape index out of range");
+      B.var[k].shape = bd.shape[k];
+      mass_variant(S->shapes[bd.shape[k]], bd.density, &B.var[k]);
+    }
+    if (bd.n_choices == 1) B.var[1] = B.var[0];
+    B.friction = bd.friction;
+    B.restitution = bd.restitution;
+    B.linearDamping = bd.linear_damping;
+    B.angularDamping = bd.angular_damping;
+    B.cat = bd.category_bits;
+    B.mask = bd.mask_bits;
+    B.nJoints = 0;
+  }
+  for (int j = 0; j < d.n_joints; ++j) {
+    const blcd_joint_def& jd = d.joints[j];
+    if (jd.body_a < 0 || jd.body_a >= d.n_bodies || jd.body_b < 0 || jd.body_b >= d.n_bodies || jd.body_a == jd.body_b)
+      return fail(BLCD_ERR_INVALID, "joint body index out of range");
+    DevJoint& J = S->joints[j];
+    J.bodyA = jd.body_a;
+    J.bodyB = jd.body_b;
+    J.anchorA = V2(jd.anchor_a[0], jd.anchor_a[1]);
+    J.anchorB = V2(jd.anchor_b[0], jd.anchor_b[1]);
+    J.enableLimit = jd.enable_limit;
+    J.lower = jd.lower;
+    J.upper = jd.upper;
+    J.maxMotorTorque = jd.max_motor_torque;
+    J.speed = jd.speed;
+    J.actionIndex = jd.action_index;
+    if (jd.action_index >= d.n_act) return fail(BLCD_ERR_INVALID, "joint action_index out of range");
+  }
+  // joint-edge lists, newest first
+  for (int j = d.n_joints - 1; j >= 0; --j) {
+    int ends[2] = {S->joints[j].bodyA, S->joints[j].bodyB};
+    for (int k = 0; k < 2; ++k) {
+      DevBody& B = S->bodies[ends[k]];
+      if (B.nJoints >= 8) return fail(BLCD_ERR_UNSUPPORTED, "more than 8 joints on one body");
+      B.joints[B.nJoints++] = j;
+    }
+  }
+  // pair slots: (A,B)-sorted proxies that AddPair can accept (b2Body::ShouldCollide + b2ContactFilter::ShouldCollide)
+  int np = 0;
+  int total = 4 + d.n_bodies;
+  for (int a = 0; a < total; ++a)
+    for (int b = a + 1; b < total; ++b) {
+      if (b < 4) continue;  // both static
+      uint32_t catA = a < 4 ? 0x0001u : S->bodies[a - 4].cat, maskA = a < 4 ? 0xFFFFu : S->bodies[a - 4].mask;
+      uint32_t catB = S->bodies[b - 4].cat, maskB = S->bodies[b - 4].mask;
+      float fricA = a < 4 ? 0.2f : S->bodies[a - 4].friction, restA = a < 4 ? 0.0f : S->bodies[a - 4].restitution;
+      float fricB = S->bodies[b - 4].friction, restB = S->bodies[b - 4].restitution;
+      bool jointed = false;
+      if (a >= 4)
+        for (int j = 0; j < d.n_joints; ++j) {
+          int ja = S->joints[j].bodyA + 4, jb = S->joints[j].bodyB + 4;
+          if ((ja == a && jb == b) || (ja == b && jb == a)) jointed = true;
+        }
+      if (jointed) continue;
+      if (!((maskA & catB) != 0 && (catA & maskB) != 0)) continue;
+      if (np >= kMaxPairs) return fail(BLCD_ERR_UNSUPPORTED, "scene has more than 100 collidable pairs");
+      DevPair& P = S->pairs[np++];
+      P.a = a;
+      P.b = b;
+      P.friction = sqrtf(fricA * fricB);                 // b2MixFriction (argument order: fixtureA, fixtureB)
+      P.restitution = restA > restB ? restA : restB;     // b2MixRestitution
+    }
+  S->np = np;
+  for (int i = 0; i < d.n_obs; ++i) {
+    const blcd_obs_def& od = d.obs[i];
+    if (od.body < 0 || od.body >= d.n_bodies || od.kind < 0 || od.kind > 5) return fail(BLCD_ERR_INVALID, "bad obs entry");
+    S->obs[i].kind = od.kind;
+    S->obs[i].body = od.body;
+    S->obs[i].lo = od.lo;
+    S->obs[i].hi = od.hi;
+  }
+  return BLCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------------------
+struct blcd_handle_s {
+  int device = 0;
+  int N = 0;
+  DevScene hostScene;
+  DevScene* dScene = nullptr;
+  float* st = nullptr;
+  size_t words = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float lastMs = 0.0f;
+  int lastLaunches = 0;
+  // staging
+  void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stageBytes[4] = {0, 0, 0, 0};
+  int cfg = -1;
+};
+
+static int ensure_stage(blcd_handle h, int k, size_t bytes) {
+  if (h->stageBytes[k] >= bytes) return BLCD_OK;
+  if (h->stage[k]) HIPCHK(hipFree(h->stage[k]));
+  h->stage[k] = nullptr;
+  h->stageBytes[k] = 0;
+  HIPCHK(hipMalloc(&h->stage[k], bytes));
+  h->stageBytes[k] = bytes;
+  return BLCD_OK;
+}
+
+static bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// returns a device pointer holding `bytes` of input data (staged if `p` is host memory)
+static int in_ptr(blcd_handle h, int k, const void* p, size_t bytes, const void** out) {
+  if (!p) {
+    *out = nullptr;
+    return BLCD_OK;
+  }
+  if (is_device_ptr(p)) {
+    *out = p;
+    return BLCD_OK;
+  }
+  int rc = ensure_stage(h, k, bytes);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->stage[k], p, bytes, hipMemcpyHostToDevice, h->stream));
+  *out = h->stage[k];
+  return BLCD_OK;
+}
+// returns a device pointer to write `bytes` into; if `p` is host memory the caller must call out_done afterwards
+static int out_ptr(blcd_handle h, int k, void* p, size_t bytes, void** out) {
+  if (!p) {
+    *out = nullptr;
+    return BLCD_OK;
+  }
+  if (is_device_ptr(p)) {
+    *out = p;
+    return BLCD_OK;
+  }
+  int rc = ensure_stage(h, k, bytes);
+  if (rc) return rc;
+  *out = h->stage[k];
+  return BLCD_OK;
+}
+static int out_done(blcd_handle h, int k, void* p, size_t bytes, void* dev) {
+  if (!p || dev == p) return BLCD_OK;
+  HIPCHK(hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+
+// ---- template dispatch over (max bodies, max joints, max pair slots) -------------------------------------
+#define BLCD_CONFIGS(X) X(1, 0, 4) X(2, 0, 9) X(3, 0, 15) X(4, 3, 16) X(5, 3, 24) X(7, 3, 44) X(20, 20, 100)
+struct Cfg {
+  int nb, nj, np;
+};
+static const Cfg kCfgs[] = {
+#define X(a, b, c) {a, b, c},
+    BLCD_CONFIGS(X)
+#undef X
+};
+static int pick_cfg(const DevScene& S) {
+  for (size_t i = 0; i < sizeof(kCfgs) / sizeof(kCfgs[0]); ++i)
+    if (S.nb <= kCfgs[i].nb && S.nj <= kCfgs[i].nj && S.np <= kCfgs[i].np) return (int)i;
+  return -1;
+}
+
+static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors) {
+  dim3 grid((h->N + kBlock - 1) / kBlock), block(kBlock);
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  int idx = 0;
+#define X(a, b, c)                                                                                              \
+  if (h->cfg == idx)                                                                                            \
+    hipLaunchKernelGGL((step_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dActions, nEnvSteps, \
+                       nWorldSteps, setMotors);                                                                 \
+  ++idx;
+  BLCD_CONFIGS(X)
+#undef X
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  h->lastLaunches += 1;
+  return BLCD_OK;
+}
+
+static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* dPoses, const uint8_t* dMask) {
+  dim3 grid((n + 63) / 64), block(64);
+  int idx = 0;
+#define X(a, b, c)                                                                                                  \
+  if (h->cfg == idx)                                                                                                \
+    hipLaunchKernelGGL((set_poses_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dIdx, n, dPoses, dMask); \
+  ++idx;
+  BLCD_CONFIGS(X)
+#undef X
+  HIPCHK(hipGetLastError());
+  return BLCD_OK;
+}
+
+template <typename ObsT>
+static int launch_obs(blcd_handle h, ObsT* dObs, uint8_t* dLcd) {
+  dim3 grid((h->N + kBlock - 1) / kBlock), block(kBlock);
+  if (h->hostScene.lcdH == 16)
+    hipLaunchKernelGGL((obs_kernel<16, uint32_t, ObsT>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dObs, dLcd, h->st);
+  else
+    hipLaunchKernelGGL((obs_kernel<32, uint64_t, ObsT>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dObs, dLcd, h->st);
+  HIPCHK(hipGetLastError());
+  return BLCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int blcd_version(void) { return BLCD_VERSION; }
+const char* blcd_last_error(void) { return g_err.c_str(); }
+int blcd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, blcd_handle* out) {
+  if (!scene || !out || n_envs < 1) return fail(BLCD_ERR_INVALID, "blcd_create: bad arguments");
+  int ndev = blcd_device_count();
+  if (ndev <= 0) return fail(BLCD_ERR_NO_DEVICE, "no HIP device available (boxlcd_hip has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(BLCD_ERR_NO_DEVICE, "device index out of range");
+  blcd_handle h = new blcd_handle_s();
+  int rc = lower_scene(*scene, &h->hostScene);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  h->cfg = pick_cfg(h->hostScene);
+  if (h->cfg < 0) {
+    delete h;
+    return fail(BLCD_ERR_UNSUPPORTED, "scene exceeds the compiled kernel configurations");
+  }
+  h->device = device;
+  h->N = n_envs;
+  h->words = (size_t)stateWords(h->hostScene.nb, h->hostScene.nj, h->hostScene.np);
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipEventCreate(&h->ev1));
+  HIPCHK(hipMalloc((void**)&h->dScene, sizeof(DevScene)));
+  HIPCHK(hipMemcpy(h->dScene, &h->hostScene, sizeof(DevScene), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&h->st, h->words * (size_t)n_envs * sizeof(float)));
+  HIPCHK(hipMemset(h->st, 0, h->words * (size_t)n_envs * sizeof(float)));
+  *out = h;
+  return BLCD_OK;
+}
+
+int blcd_destroy(blcd_handle h) {
+  if (!h) return BLCD_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int k = 0; k < 4; ++k)
+    if (h->stage[k]) (void)hipFree(h->stage[k]);
+  if (h->st) (void)hipFree(h->st);
+  if (h->dScene) (void)hipFree(h->dScene);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return BLCD_OK;
+}
+
+int blcd_num_envs(blcd_handle h) { return h ? h->N : 0; }
+int blcd_num_pairs(blcd_handle h) { return h ? h->hostScene.np : 0; }
+int blcd_pair_table(blcd_handle h, int32_t* pairs) {
+  if (!h || !pairs) return fail(BLCD_ERR_INVALID, "blcd_pair_table: bad arguments");
+  for (int i = 0; i < h->hostScene.np; ++i) {
+    pairs[2 * i] = h->hostScene.pairs[i].a;
+    pairs[2 * i + 1] = h->hostScene.pairs[i].b;
+  }
+  return BLCD_OK;
+}
+
+int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const int32_t* shape_sel) {
+  if (!h || !poses || n < 1) return fail(BLCD_ERR_INVALID, "blcd_reset: bad arguments");
+  if (!idxs && n != h->N) return fail(BLCD_ERR_INVALID, "blcd_reset: idxs == NULL requires n == n_envs");
+  HIPCHK(hipSetDevice(h->device));
+  const int nb = h->hostScene.nb;
+  const void *dIdx, *dPoses, *dSel;
+  int rc;
+  if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
+  if ((rc = in_ptr(h, 1, poses, (size_t)n * nb * 3 * sizeof(float), &dPoses))) return rc;
+  if ((rc = in_ptr(h, 2, shape_sel, (size_t)n * nb * sizeof(int32_t), &dSel))) return rc;
+  hipLaunchKernelGGL(reset_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (const int*)dIdx, n,
+                     (const float*)dPoses, (const int*)dSel);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+
+int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const uint8_t* mask) {
+  if (!h || !poses || n < 1) return fail(BLCD_ERR_INVALID, "blcd_set_poses: bad arguments");
+  if (!idxs && n != h->N) return fail(BLCD_ERR_INVALID, "blcd_set_poses: idxs == NULL requires n == n_envs");
+  HIPCHK(hipSetDevice(h->device));
+  const int nb = h->hostScene.nb;
+  const void *dIdx, *dPoses, *dMask;
+  int rc;
+  if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
+  if ((rc = in_ptr(h, 1, poses, (size_t)n * nb * 3 * sizeof(float), &dPoses))) return rc;
+  if ((rc = in_ptr(h, 2, mask, (size_t)nb, &dMask))) return rc;
+  if ((rc = launch_set_poses(h, (const int*)dIdx, n, (const float*)dPoses, (const uint8_t*)dMask))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+
+int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
+  if (!h || n_steps < 0) return fail(BLCD_ERR_INVALID, "blcd_step: bad arguments");
+  if (n_steps == 0) return BLCD_OK;
+  HIPCHK(hipSetDevice(h->device));
+  const void* dAct;
+  int rc;
+  if ((rc = in_ptr(h, 0, actions, (size_t)h->N * h->hostScene.nact * sizeof(float), &dAct))) return rc;
+  h->lastLaunches = 0;
+  if ((rc = launch_step(h, (const float*)dAct, n_steps, 0, 0))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipEventElapsedTime(&h->lastMs, h->ev0, h->ev1));
+  return BLCD_OK;
+}
+
+int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out) {
+  if (!h || T < 1) return fail(BLCD_ERR_INVALID, "blcd_rollout: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const int nact = h->hostScene.nact, nobs = h->hostScene.nobs;
+  const size_t lcdStep = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW;
+  const size_t obsStep = (size_t)h->N * nobs;
+  const void* dAct;
+  void *dLcd, *dObs;
+  int rc;
+  if ((rc = in_ptr(h, 0, actions, (size_t)T * h->N * nact * sizeof(float), &dAct))) return rc;
+  if ((rc = out_ptr(h, 1, lcd_out, lcdStep * T, &dLcd))) return rc;
+  if ((rc = out_ptr(h, 2, obs_out, obsStep * T * sizeof(float), &dObs))) return rc;
+  h->lastLaunches = 0;
+  float total = 0.0f;
+  for (int t = 0; t < T; ++t) {
+    const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
+    if ((rc = launch_step(h, a, 1, 0, 0))) return rc;
+    if (dLcd || dObs) {
+      if ((rc = launch_obs<float>(h, dObs ? (float*)dObs + obsStep * t : nullptr, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr)))
+        return rc;
+    }
+    // per-launch kernel time: events are re-recorded each step, so read them before the next record
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    total += ms;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->lastMs = total;
+  if ((rc = out_done(h, 1, lcd_out, lcdStep * T, dLcd))) return rc;
+  if ((rc = out_done(h, 2, obs_out, obsStep * T * sizeof(float), dObs))) return rc;
+  return BLCD_OK;
+}
+
+int blcd_get_obs(blcd_handle h, void* full_state, int32_t dtype, uint8_t* lcd) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_get_obs: bad handle");
+  if (dtype != 0 && dtype != 1) return fail(BLCD_ERR_INVALID, "blcd_get_obs: dtype must be 0 (f32) or 1 (f64)");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t obsBytes = (size_t)h->N * h->hostScene.nobs * (dtype ? 8 : 4);
+  const size_t lcdBytes = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW;
+  void *dObs, *dLcd;
+  int rc;
+  if ((rc = out_ptr(h, 1, full_state, obsBytes, &dObs))) return rc;
+  if ((rc = out_ptr(h, 2, lcd, lcdBytes, &dLcd))) return rc;
+  if (dtype) rc = launch_obs<double>(h, (double*)dObs, (uint8_t*)dLcd);
+  else rc = launch_obs<float>(h, (float*)dObs, (uint8_t*)dLcd);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if ((rc = out_done(h, 1, full_state, obsBytes, dObs))) return rc;
+  if ((rc = out_done(h, 2, lcd, lcdBytes, dLcd))) return rc;
+  return BLCD_OK;
+}
+
+int blcd_render_poses(blcd_handle h, const float* poses, const int32_t* shape_sel, int32_t m, uint8_t* lcd) {
+  if (!h || !poses || !lcd || m < 1) return fail(BLCD_ERR_INVALID, "blcd_render_poses: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const int nb = h->hostScene.nb;
+  const size_t lcdBytes = (size_t)m * h->hostScene.lcdH * h->hostScene.lcdW;
+  const void *dPoses, *dSel;
+  void* dLcd;
+  int rc;
+  if ((rc = in_ptr(h, 0, poses, (size_t)m * nb * 3 * sizeof(float), &dPoses))) return rc;
+  if ((rc = in_ptr(h, 1, shape_sel, (size_t)m * nb * sizeof(int32_t), &dSel))) return rc;
+  if ((rc = out_ptr(h, 2, lcd, lcdBytes, &dLcd))) return rc;
+  dim3 grid((m + 63) / 64), block(64);
+  if (h->hostScene.lcdH == 16)
+    hipLaunchKernelGGL((render_poses_kernel<16, uint32_t>), grid, block, 0, h->stream, h->dScene, m, (const float*)dPoses,
+                       (const int*)dSel, (uint8_t*)dLcd);
+  else
+    hipLaunchKernelGGL((render_poses_kernel<32, uint64_t>), grid, block, 0, h->stream, h->dScene, m, (const float*)dPoses,
+                       (const int*)dSel, (uint8_t*)dLcd);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return out_done(h, 2, lcd, lcdBytes, dLcd);
+}
+
+int blcd_get_poses(blcd_handle h, float* poses) {
+  if (!h || !poses) return fail(BLCD_ERR_INVALID, "blcd_get_poses: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->N * h->hostScene.nb * 4 * sizeof(float);
+  void* d;
+  int rc;
+  if ((rc = out_ptr(h, 1, poses, bytes, &d))) return rc;
+  hipLaunchKernelGGL(poses_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (float*)d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return out_done(h, 1, poses, bytes, d);
+}
+
+struct StateHeader {
+  uint32_t magic, version;
+  int32_t n, nb, nj, np;
+  uint64_t words;
+};
+int blcd_get_state(blcd_handle h, void* blob, size_t* size) {
+  if (!h || !size) return fail(BLCD_ERR_INVALID, "blcd_get_state: bad arguments");
+  size_t need = sizeof(StateHeader) + h->words * (size_t)h->N * sizeof(float);
+  if (!blob) {
+    *size = need;
+    return BLCD_OK;
+  }
+  if (*size < need) return fail(BLCD_ERR_INVALID, "blcd_get_state: buffer too small");
+  HIPCHK(hipSetDevice(h->device));
+  StateHeader hd = {0x44434c42u, BLCD_VERSION, h->N, h->hostScene.nb, h->hostScene.nj, h->hostScene.np, (uint64_t)h->words};
+  std::memcpy(blob, &hd, sizeof(hd));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy((char*)blob + sizeof(hd), h->st, need - sizeof(hd), hipMemcpyDeviceToHost));
+  *size = need;
+  return BLCD_OK;
+}
+int blcd_set_state(blcd_handle h, const void* blob, size_t size) {
+  if (!h || !blob) return fail(BLCD_ERR_INVALID, "blcd_set_state: bad arguments");
+  size_t need = sizeof(StateHeader) + h->words * (size_t)h->N * sizeof(float);
+  if (size != need) return fail(BLCD_ERR_INVALID, "blcd_set_state: size mismatch");
+  StateHeader hd;
+  std::memcpy(&hd, blob, sizeof(hd));
+  if (hd.magic != 0x44434c42u || hd.n != h->N || hd.nb != h->hostScene.nb || hd.nj != h->hostScene.nj ||
+      hd.np != h->hostScene.np || hd.words != h->words)
+    return fail(BLCD_ERR_INVALID, "blcd_set_state: snapshot belongs to a different scene/batch");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->st, (const char*)blob + sizeof(hd), need - sizeof(hd), hipMemcpyHostToDevice));
+  return BLCD_OK;
+}
+
+int blcd_get_faults(blcd_handle h, int32_t* flags) {
+  if (!h || !flags) return fail(BLCD_ERR_INVALID, "blcd_get_faults: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->N * sizeof(int32_t);
+  int rc = ensure_stage(h, 3, bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(faults_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (int*)h->stage[3]);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(flags, h->stage[3], bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+
+int blcd_sync(blcd_handle h) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_sync: bad handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+void* blcd_stream(blcd_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_last_kernel_ms: bad handle");
+  if (ms) *ms = h->lastMs;
+  if (launches) *launches = h->lastLaunches;
+  return BLCD_OK;
+}
+
+int blcd_debug_world_step(blcd_handle h, int32_t n) {
+  if (!h || n < 0) return fail(BLCD_ERR_INVALID, "blcd_debug_world_step: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = launch_step(h, nullptr, 0, n, 0);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+int blcd_debug_set_motor_speeds(blcd_handle h, const float* actions) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_debug_set_motor_speeds: bad handle");
+  HIPCHK(hipSetDevice(h->device));
+  const void* dAct;
+  int rc;
+  if ((rc = in_ptr(h, 0, actions, (size_t)h->N * h->hostScene.nact * sizeof(float), &dAct))) return rc;
+  if ((rc = launch_step(h, (const float*)dAct, 0, 0, 1))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+int blcd_debug_dump(blcd_handle h, float* bodies, float* joints, float* pairs) {
+  if (!h || !bodies || !joints || !pairs) return fail(BLCD_ERR_INVALID, "blcd_debug_dump: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const DevScene& S = h->hostScene;
+  size_t bb = (size_t)h->N * S.nb * BLCD_BODY_STATE_FLOATS * 4;
+  size_t jb = (size_t)h->N * (S.nj > 0 ? S.nj : 1) * BLCD_JOINT_STATE_FLOATS * 4;
+  size_t pb = (size_t)h->N * (S.np > 0 ? S.np : 1) * BLCD_PAIR_STATE_FLOATS * 4;
+  int rc;
+  if ((rc = ensure_stage(h, 1, bb))) return rc;
+  if ((rc = ensure_stage(h, 2, jb))) return rc;
+  if ((rc = ensure_stage(h, 3, pb))) return rc;
+  hipLaunchKernelGGL(dump_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (float*)h->stage[1],
+                     (float*)h->stage[2], (float*)h->stage[3]);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(bodies, h->stage[1], bb, hipMemcpyDeviceToHost, h->stream));
+  if (S.nj > 0) HIPCHK(hipMemcpyAsync(joints, h->stage[2], (size_t)h->N * S.nj * BLCD_JOINT_STATE_FLOATS * 4, hipMemcpyDeviceToHost, h->stream));
+  if (S.np > 0) HIPCHK(hipMemcpyAsync(pairs, h->stage[3], (size_t)h->N * S.np * BLCD_PAIR_STATE_FLOATS * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+
+int blcd_debug_sincos(const float* x, int64_t n, float* s, float* c, int32_t device) {
+  if (!x || !s || !c || n < 1) return fail(BLCD_ERR_INVALID, "blcd_debug_sincos: bad arguments");
+  if (blcd_device_count() <= 0) return fail(BLCD_ERR_NO_DEVICE, "no HIP device available");
+  HIPCHK(hipSetDevice(device));
+  float *dx, *ds, *dc;
+  HIPCHK(hipMalloc((void**)&dx, n * 4));
+  HIPCHK(hipMalloc((void**)&ds, n * 4));
+  HIPCHK(hipMalloc((void**)&dc, n * 4));
+  HIPCHK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(sincos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, n, ds, dc);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(s, ds, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(c, dc, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(dx);
+  (void)hipFree(ds);
+  (void)hipFree(dc);
+  return BLCD_OK;
+}
+
+int blcd_debug_mass_data(const blcd_scene_desc* scene, int32_t shape, float density, float* out) {
+  if (!scene || !out || shape < 0 || shape >= scene->n_shapes) return fail(BLCD_ERR_INVALID, "blcd_debug_mass_data: bad arguments");
+  Shape s = build_shape(scene->shapes[shape]);
+  MassData md;
+  ShapeComputeMass(&s, &md, density);
+  out[0] = md.mass;
+  out[1] = md.center.x;
+  out[2] = md.center.y;
+  out[3] = md.I;
+  out[4] = (float)s.count;
+  for (int i = 0; i < s.count && i < 8; ++i) {
+    out[5 + 2 * i] = s.v[i].x;
+    out[6 + 2 * i] = s.v[i].y;
+  }
+  return BLCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1373 @@
+// blcd_world.h — device-side world step of the HIP product: one thread advances one environment.
+//
+// Replaces `b2World.Step(dt, 180, 60)` as called 3x per env step at boxLCD/world_env.py:448-450 (Box2D 2.3.x
+// semantics: b2World::Step / b2ContactManager::Collide / b2World::Solve / b2Island::Solve / b2ContactSolver /
+// b2RevoluteJoint / b2World::SolveTOI / b2Island::SolveTOI; SURVEY.md §8 a3.*).
+//
+// Design (not Box2D's): boxLCD scenes are tiny and their topology is static, so instead of dynamic trees, lists and
+// allocators an environment is a fixed set of *pair slots* — every (proxy A, proxy B) combination that Box2D's
+// AddPair could ever accept for the scene (not both static, not joint-connected, category/mask filter), enumerated in
+// (A,B)-sorted order on the host.  Box2D's order-defining structures collapse to:
+//   * world contact list / body contact-edge lists  -> one newest-first array of slot ids (`wl`)
+//   * broad-phase move buffer                        -> a bit mask of dynamic bodies
+//   * islands                                        -> bit masks + a slot list in DFS order
+// Walls (proxies 0..3) are constants: identity transform, zero velocity, zero inverse mass.
+// State lives SoA in HBM ([field][env], env fastest => coalesced 256 B lines per wave) and is staged into
+// per-thread storage for the duration of a launch.
+#pragma once
+#include "blcd_toi.h"
+
+namespace blcd {
+
+constexpr int kMaxPairs = 100;
+constexpr int kBodyFields = 18;   // c.xy a v.xy w c0.xy a0 xf.p.xy sleepTime awake fat.lo.xy fat.hi.xy sel
+constexpr int kPairFields = 17;   // flags type|count ln.xy lp.xy {lp.xy ni ti id}x2
+constexpr int kJointFields = 7;   // impulse.xyz motorImpulse limitState motorSpeed referenceAngle
+constexpr int kWorldFields = 4;   // inv_dt0 moveMask flags nc   (+ wl packed 4 slots per word)
+
+enum { PF_EXISTS = 1, PF_TOUCHING = 2, PF_ENABLED = 4, PF_ISLAND = 8, PF_TOI = 16 };
+enum { WF_NEWFIXTURE = 1 };
+enum { FAULT_NAN = 1, FAULT_ELLIPSE = 2, FAULT_OVERFLOW = 4 };
+enum { kInactiveLimit = 0, kAtLowerLimit = 1, kAtUpperLimit = 2, kEqualLimits = 3 };
+
+struct DevVariant {
+  int shape;
+  float mass, invMass, I, invI;
+  Vec2 localCenter;
+};
+struct DevBody {
+  int nChoices;
+  DevVariant var[2];
+  float friction, restitution, linearDamping, angularDamping;
+  uint32_t cat, mask;
+  int nJoints;
+  int joints[8];  // joint-edge list, newest first (b2Body::m_jointList order)
+};
+struct DevJoint {
+  int bodyA, bodyB;  // dynamic-body indices
+  Vec2 anchorA, anchorB;
+  int enableLimit;
+  float lower, upper, maxMotorTorque, speed;
+  int actionIndex;
+};
+struct DevPair {
+  int a, b;  // proxy ids, a < b; a < 4 => wall
+  float friction, restitution;
+};
+struct DevObs {
+  int kind, body;
+  float lo, hi;
+};
+struct DevScene {
+  int nb, nj, np, nobs, nact, lcdW, lcdH, rasterVariant;
+  float worldW, worldH;
+  Vec2 gravity;
+  float dt;
+  int substeps, velIters, posIters;
+  int nShapes;
+  Shape wallShape[4];
+  AABB wallFat[4];
+  Shape shapes[24];
+  DevBody bodies[20];
+  DevJoint joints[20];
+  DevPair pairs[kMaxPairs];
+  DevObs obs[96];
+};
+
+BLCD_HD static inline int stateWords(int nb, int nj, int np) {
+  return nb * kBodyFields + np * kPairFields + nj * kJointFields + kWorldFields + (np + 3) / 4;
+}
+
+struct VCPoint {
+  Vec2 rA, rB;
+  float normalImpulse, tangentImpulse, normalMass, tangentMass, velocityBias;
+};
+struct VC {
+  VCPoint points[2];
+  Vec2 normal;
+  Mat22 normalMass, K;
+  int slot, pA, pB;  // proxy ids of fixture A / B
+  float friction, restitution;
+  int pointCount;
+};
+
+template <int NB, int NJ, int NP>
+struct Env {
+  const DevScene* S;
+  // --- dynamic bodies ---
+  Vec2 c[NB], v[NB], c0[NB], xfp[NB];
+  float a[NB], w[NB], a0[NB], sleepTime[NB], alpha0[NB];
+  Rot q[NB];
+  AABB fat[NB];
+  int sel[NB];
+  uint32_t awakeMask;
+  float invMass[NB], invI[NB];
+  Vec2 lc[NB];
+  // --- pair slots ---
+  uint8_t wl[NP];
+  int nc;
+  uint8_t pflags[NP];
+  uint8_t toiCount[NP];
+  float toi[NP];
+  Manifold man[NP];
+  // --- joints ---
+  Vec3 jimp[NJ > 0 ? NJ : 1];
+  float jmotor[NJ > 0 ? NJ : 1], jspeed[NJ > 0 ? NJ : 1], jref[NJ > 0 ? NJ : 1];
+  int jlimit[NJ > 0 ? NJ : 1];
+  // joint solver temporaries
+  Vec2 jrA[NJ > 0 ? NJ : 1], jrB[NJ > 0 ? NJ : 1];
+  Mat33 jmass[NJ > 0 ? NJ : 1];
+  float jmotorMass[NJ > 0 ? NJ : 1];
+  // --- world ---
+  float inv_dt0;
+  uint32_t moveMask;
+  uint32_t wflags;
+  int fault;
+  float wallAlpha0[4];
+  // --- island scratch ---
+  Vec2 pc[NB], pv[NB];
+  float pa[NB], pw[NB];
+  VC vc[NP];
+  uint8_t ic[NP];
+  uint8_t ij[NJ > 0 ? NJ : 1];
+
+  // ------------------------------------------------------------------------------------------------
+  // SoA state <-> thread
+  // ------------------------------------------------------------------------------------------------
+  __device__ void load(const DevScene* scene, const float* __restrict__ st, int N, int e) {
+    S = scene;
+    const int nb = S->nb, nj = S->nj, np = S->np;
+    awakeMask = 0;
+    for (int i = 0; i < NB; ++i) {
+      if (i >= nb) break;
+      const float* p = st + (size_t)(i * kBodyFields) * N + e;
+      c[i] = V2(p[0], p[(size_t)1 * N]);
+      a[i] = p[(size_t)2 * N];
+      v[i] = V2(p[(size_t)3 * N], p[(size_t)4 * N]);
+      w[i] = p[(size_t)5 * N];
+      c0[i] = V2(p[(size_t)6 * N], p[(size_t)7 * N]);
+      a0[i] = p[(size_t)8 * N];
+      xfp[i] = V2(p[(size_t)9 * N], p[(size_t)10 * N]);
+      sleepTime[i] = p[(size_t)11 * N];
+      if (p[(size_t)12 * N] != 0.0f) awakeMask |= 1u << i;
+      fat[i].lo = V2(p[(size_t)13 * N], p[(size_t)14 * N]);
+      fat[i].hi = V2(p[(size_t)15 * N], p[(size_t)16 * N]);
+      sel[i] = __float_as_int(p[(size_t)17 * N]);
+      q[i].Set(a[i]);
+      alpha0[i] = 0.0f;
+      const DevVariant& var = S->bodies[i].var[sel[i]];
+      invMass[i] = var.invMass;
+      invI[i] = var.invI;
+      lc[i] = var.localCenter;
+    }
+    const float* pp = st + (size_t)(nb * kBodyFields) * N + e;
+    for (int s = 0; s < NP; ++s) {
+      if (s >= np) break;
+      const float* p = pp + (size_t)(s * kPairFields) * N;
+      int fl = __float_as_int(p[0]);
+      pflags[s] = (uint8_t)fl;
+      int tc = __float_as_int(p[(size_t)1 * N]);
+      Manifold& m = man[s];
+      m.type = tc & 0xff;
+      m.pointCount = tc >> 8;
+      m.localNormal = V2(p[(size_t)2 * N], p[(size_t)3 * N]);
+      m.localPoint = V2(p[(size_t)4 * N], p[(size_t)5 * N]);
+      for (int k = 0; k < 2; ++k) {
+        const float* r = p + (size_t)(6 + 5 * k) * N;
+        m.points[k].localPoint = V2(r[0], r[(size_t)1 * N]);
+        m.points[k].normalImpulse = r[(size_t)2 * N];
+        m.points[k].tangentImpulse = r[(size_t)3 * N];
+        m.points[k].id.key = __float_as_uint(r[(size_t)4 * N]);
+      }
+      toiCount[s] = 0;
+      toi[s] = 1.0f;
+    }
+    const float* jp = pp + (size_t)(np * kPairFields) * N;
+    for (int j = 0; j < NJ; ++j) {
+      if (j >= nj) break;
+      const float* p = jp + (size_t)(j * kJointFields) * N;
+      jimp[j] = Vec3{p[0], p[(size_t)1 * N], p[(size_t)2 * N]};
+      jmotor[j] = p[(size_t)3 * N];
+      jlimit[j] = __float_as_int(p[(size_t)4 * N]);
+      jspeed[j] = p[(size_t)5 * N];
+      jref[j] = p[(size_t)6 * N];
+    }
+    const float* wp = jp + (size_t)(nj * kJointFields) * N;
+    inv_dt0 = wp[0];
+    moveMask = __float_as_uint(wp[(size_t)1 * N]);
+    uint32_t fl = __float_as_uint(wp[(size_t)2 * N]);
+    wflags = fl & 0xff;
+    fault = (int)(fl >> 8);
+    nc = __float_as_int(wp[(size_t)3 * N]);
+    for (int k = 0; k < (NP + 3) / 4; ++k) {
+      if (4 * k >= np) break;
+      uint32_t word = __float_as_uint(wp[(size_t)(4 + k) * N]);
+      for (int t = 0; t < 4; ++t)
+        if (4 * k + t < NP) wl[4 * k + t] = (uint8_t)(word >> (8 * t));
+    }
+    for (int k = 0; k < 4; ++k) wallAlpha0[k] = 0.0f;
+  }
+
+  __device__ void store(float* __restrict__ st, int N, int e) {
+    const int nb = S->nb, nj = S->nj, np = S->np;
+    for (int i = 0; i < NB; ++i) {
+      if (i >= nb) break;
+      float* p = st + (size_t)(i * kBodyFields) * N + e;
+      p[0] = c[i].x;
+      p[(size_t)1 * N] = c[i].y;
+      p[(size_t)2 * N] = a[i];
+      p[(size_t)3 * N] = v[i].x;
+      p[(size_t)4 * N] = v[i].y;
+      p[(size_t)5 * N] = w[i];
+      p[(size_t)6 * N] = c0[i].x;
+      p[(size_t)7 * N] = c0[i].y;
+      p[(size_t)8 * N] = a0[i];
+      p[(size_t)9 * N] = xfp[i].x;
+      p[(size_t)10 * N] = xfp[i].y;
+      p[(size_t)11 * N] = sleepTime[i];
+      p[(size_t)12 * N] = (awakeMask >> i) & 1 ? 1.0f : 0.0f;
+      p[(size_t)13 * N] = fat[i].lo.x;
+      p[(size_t)14 * N] = fat[i].lo.y;
+      p[(size_t)15 * N] = fat[i].hi.x;
+      p[(size_t)16 * N] = fat[i].hi.y;
+      // sel is immutable during stepping
+    }
+    float* pp = st + (size_t)(nb * kBodyFields) * N + e;
+    for (int s = 0; s < NP; ++s) {
+      if (s >= np) break;
+      float* p = pp + (size_t)(s * kPairFields) * N;
+      p[0] = __int_as_float((int)(pflags[s] & (PF_EXISTS | PF_TOUCHING | PF_ENABLED)));
+      const Manifold& m = man[s];
+      p[(size_t)1 * N] = __int_as_float((m.type & 0xff) | (m.pointCount << 8));
+      p[(size_t)2 * N] = m.localNormal.x;
+      p[(size_t)3 * N] = m.localNormal.y;
+      p[(size_t)4 * N] = m.localPoint.x;
+      p[(size_t)5 * N] = m.localPoint.y;
+      for (int k = 0; k < 2; ++k) {
+        float* r = p + (size_t)(6 + 5 * k) * N;
+        r[0] = m.points[k].localPoint.x;
+        r[(size_t)1 * N] = m.points[k].localPoint.y;
+        r[(size_t)2 * N] = m.points[k].normalImpulse;
+        r[(size_t)3 * N] = m.points[k].tangentImpulse;
+        r[(size_t)4 * N] = __uint_as_float(m.points[k].id.key);
+      }
+    }
+    float* jp = pp + (size_t)(np * kPairFields) * N;
+    for (int j = 0; j < NJ; ++j) {
+      if (j >= nj) break;
+      float* p = jp + (size_t)(j * kJointFields) * N;
+      p[0] = jimp[j].x;
+      p[(size_t)1 * N] = jimp[j].y;
+      p[(size_t)2 * N] = jimp[j].z;
+      p[(size_t)3 * N] = jmotor[j];
+      p[(size_t)4 * N] = __int_as_float(jlimit[j]);
+      p[(size_t)5 * N] = jspeed[j];
+      // jref immutable
+    }
+    float* wp = jp + (size_t)(nj * kJointFields) * N;
+    wp[0] = inv_dt0;
+    wp[(size_t)1 * N] = __uint_as_float(moveMask);
+    wp[(size_t)2 * N] = __uint_as_float((wflags & 0xff) | ((uint32_t)fault << 8));
+    wp[(size_t)3 * N] = __int_as_float(nc);
+    for (int k = 0; k < (NP + 3) / 4; ++k) {
+      if (4 * k >= np) break;
+      uint32_t word = 0;
+      for (int t = 0; t < 4; ++t)
+        if (4 * k + t < NP) word |= (uint32_t)wl[4 * k + t] << (8 * t);
+      wp[(size_t)(4 + k) * N] = __uint_as_float(word);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // proxy accessors (proxy p: 0..3 wall, 4+i dynamic body i)
+  // ------------------------------------------------------------------------------------------------
+  __device__ Transform xfOf(int p) const {
+    Transform t;
+    if (p < 4) {
+      t.p = V2(0.0f, 0.0f);
+      t.q.s = 0.0f;
+      t.q.c = 1.0f;
+    } else {
+      t.p = xfp[p - 4];
+      t.q = q[p - 4];
+    }
+    return t;
+  }
+  __device__ const Shape* shapeOf(int p) const {
+    if (p < 4) return &S->wallShape[p];
+    int i = p - 4;
+    return &S->shapes[S->bodies[i].var[sel[i]].shape];
+  }
+  __device__ AABB fatOf(int p) const { return p < 4 ? S->wallFat[p] : fat[p - 4]; }
+  __device__ bool awakeDyn(int i) const { return (awakeMask >> i) & 1; }
+  __device__ void wake(int p) {  // b2Body::SetAwake(true); wall flags are never consulted
+    if (p < 4) return;
+    int i = p - 4;
+    if (!((awakeMask >> i) & 1)) {
+      awakeMask |= 1u << i;
+      sleepTime[i] = 0.0f;
+    }
+  }
+  __device__ void sleepBody(int i) {  // b2Body::SetAwake(false)
+    awakeMask &= ~(1u << i);
+    sleepTime[i] = 0.0f;
+    v[i] = V2(0.0f, 0.0f);
+    w[i] = 0.0f;
+  }
+  __device__ void syncTransform(int i) {  // b2Body::SynchronizeTransform
+    q[i].Set(a[i]);
+    xfp[i] = c[i] - Mul(q[i], lc[i]);
+  }
+  // fixture order of a slot after b2Contact::Create's type normalisation
+  __device__ void slotAB(int s, int* pA, int* pB) const {
+    int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+    if (pa_ >= 4) {
+      int ta = shapeOf(pa_)->type, tb = shapeOf(pb_)->type;
+      // rank: polygon(1) before circle(0)  <=> swap when A is a circle and B a polygon
+      if (ta == kCircle && tb == kPolygon) {
+        int t = pa_;
+        pa_ = pb_;
+        pb_ = t;
+      }
+    }
+    *pA = pa_;
+    *pB = pb_;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // broad phase: b2Fixture::Synchronize + b2DynamicTree::MoveProxy, b2BroadPhase::UpdatePairs, AddPair
+  // ------------------------------------------------------------------------------------------------
+  __device__ void synchronizeProxy(int i, const Transform& xf1, const Transform& xf2) {
+    const Shape* sh = shapeOf(4 + i);
+    AABB aabb1, aabb2, aabb;
+    ShapeComputeAABB(sh, &aabb1, xf1);
+    ShapeComputeAABB(sh, &aabb2, xf2);
+    aabb.lo = Min(aabb1.lo, aabb2.lo);
+    aabb.hi = Max(aabb1.hi, aabb2.hi);
+    Vec2 displacement = xf2.p - xf1.p;
+    if (fat[i].Contains(aabb)) return;
+    AABB fb = aabb;
+    Vec2 r = V2(kAabbExtension, kAabbExtension);
+    fb.lo = fb.lo - r;
+    fb.hi = fb.hi + r;
+    Vec2 d = kAabbMultiplier * displacement;
+    if (d.x < 0.0f) fb.lo.x += d.x; else fb.hi.x += d.x;
+    if (d.y < 0.0f) fb.lo.y += d.y; else fb.hi.y += d.y;
+    fat[i] = fb;
+    moveMask |= 1u << i;
+  }
+  __device__ void synchronizeFixtures(int i) {  // b2Body::SynchronizeFixtures
+    Transform xf1;
+    xf1.q.Set(a0[i]);
+    xf1.p = c0[i] - Mul(xf1.q, lc[i]);
+    synchronizeProxy(i, xf1, xfOf(4 + i));
+  }
+  __device__ void findNewContacts(bool allMoved) {
+    const int np = S->np;
+    uint32_t mm = moveMask;
+    moveMask = 0;
+    if (!allMoved && mm == 0) return;
+    for (int s = 0; s < NP; ++s) {
+      if (s >= np) break;
+      if (pflags[s] & PF_EXISTS) continue;
+      int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+      bool moved = allMoved || (pa_ >= 4 && ((mm >> (pa_ - 4)) & 1)) || ((mm >> (pb_ - 4)) & 1);
+      if (!moved) continue;
+      if (!TestOverlap(fatOf(pa_), fatOf(pb_))) continue;
+      // b2ContactManager::AddPair: new contact at the front of the world list; wake both bodies
+      for (int k = nc; k > 0; --k) wl[k] = wl[k - 1];
+      wl[0] = (uint8_t)s;
+      ++nc;
+      pflags[s] = PF_EXISTS | PF_ENABLED;
+      man[s].pointCount = 0;
+      toiCount[s] = 0;
+      toi[s] = 1.0f;
+      wake(pa_);
+      wake(pb_);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // b2Contact::Update (+ Evaluate dispatch), b2ContactManager::Collide
+  // ------------------------------------------------------------------------------------------------
+  __device__ void updateContact(int s) {
+    int pA, pB;
+    slotAB(s, &pA, &pB);
+    Manifold& m = man[s];
+    Manifold oldManifold = m;
+    pflags[s] |= PF_ENABLED;
+    bool wasTouching = (pflags[s] & PF_TOUCHING) != 0;
+    const Shape* shA = shapeOf(pA);
+    const Shape* shB = shapeOf(pB);
+    Transform xfA = xfOf(pA), xfB = xfOf(pB);
+    int ta = shA->type, tb = shB->type;
+    if (ta == kEdge) {
+      if (tb == kCircle) CollideEdgeAndCircle(&m, shA, xfA, shB, xfB);
+      else CollideEdgeAndPolygon(&m, shA, xfA, shB, xfB);
+    } else if (ta == kPolygon) {
+      if (tb == kCircle) CollidePolygonAndCircle(&m, shA, xfA, shB, xfB);
+      else CollidePolygons(&m, shA, xfA, shB, xfB);
+    } else {
+      CollideCircles(&m, shA, xfA, shB, xfB);
+    }
+    bool touching = m.pointCount > 0;
+    for (int i = 0; i < m.pointCount; ++i) {
+      ManifoldPoint* mp2 = m.points + i;
+      mp2->normalImpulse = 0.0f;
+      mp2->tangentImpulse = 0.0f;
+      uint32_t key = mp2->id.key;
+      for (int j = 0; j < oldManifold.pointCount; ++j) {
+        const ManifoldPoint* mp1 = oldManifold.points + j;
+        if (mp1->id.key == key) {
+          mp2->normalImpulse = mp1->normalImpulse;
+          mp2->tangentImpulse = mp1->tangentImpulse;
+          break;
+        }
+      }
+    }
+    if (touching != wasTouching) {
+      wake(pA);
+      wake(pB);
+    }
+    if (touching) pflags[s] |= PF_TOUCHING; else pflags[s] &= ~PF_TOUCHING;
+  }
+
+  __device__ void collide() {
+    int n = nc, out = 0;
+    for (int k = 0; k < n; ++k) {
+      int s = wl[k];
+      int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+      bool activeA = pa_ >= 4 && awakeDyn(pa_ - 4);
+      bool activeB = awakeDyn(pb_ - 4);
+      if (activeA || activeB) {
+        if (!TestOverlap(fatOf(pa_), fatOf(pb_))) {
+          // b2ContactManager::Destroy + b2Contact::Destroy
+          if (man[s].pointCount > 0) {
+            wake(pa_);
+            wake(pb_);
+          }
+          pflags[s] = 0;
+          man[s].pointCount = 0;
+          continue;
+        }
+        updateContact(s);
+      }
+      wl[out++] = (uint8_t)s;
+    }
+    nc = out;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // island state accessors: dynamic bodies from pc/pa/pv/pw, walls constant
+  // ------------------------------------------------------------------------------------------------
+  __device__ Vec2 Pc(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pc[p - 4]; }
+  __device__ float Pa(int p) const { return p < 4 ? 0.0f : pa[p - 4]; }
+  __device__ Vec2 Pv(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pv[p - 4]; }
+  __device__ float Pw(int p) const { return p < 4 ? 0.0f : pw[p - 4]; }
+  __device__ float mOf(int p) const { return p < 4 ? 0.0f : invMass[p - 4]; }
+  __device__ float iOf(int p) const { return p < 4 ? 0.0f : invI[p - 4]; }
+  __device__ Vec2 lcOf(int p) const { return p < 4 ? V2(0.0f, 0.0f) : lc[p - 4]; }
+  __device__ void setVel(int p, Vec2 vv, float ww) {
+    if (p >= 4) {
+      pv[p - 4] = vv;
+      pw[p - 4] = ww;
+    }
+  }
+  __device__ void setPos(int p, Vec2 cc, float aa) {
+    if (p >= 4) {
+      pc[p - 4] = cc;
+      pa[p - 4] = aa;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // b2ContactSolver
+  // ------------------------------------------------------------------------------------------------
+  __device__ void csInit(int count, bool warmStarting, float dtRatio) {
+    for (int i = 0; i < count; ++i) {
+      int s = ic[i];
+      VC& c_ = vc[i];
+      const Manifold& m = man[s];
+      c_.slot = s;
+      slotAB(s, &c_.pA, &c_.pB);
+      c_.friction = S->pairs[s].friction;
+      c_.restitution = S->pairs[s].restitution;
+      c_.pointCount = m.pointCount;
+      c_.K.ex = c_.K.ey = V2(0.0f, 0.0f);
+      c_.normalMass.ex = c_.normalMass.ey = V2(0.0f, 0.0f);
+      for (int j = 0; j < m.pointCount; ++j) {
+        VCPoint& p = c_.points[j];
+        if (warmStarting) {
+          p.normalImpulse = dtRatio * m.points[j].normalImpulse;
+          p.tangentImpulse = dtRatio * m.points[j].tangentImpulse;
+        } else {
+          p.normalImpulse = 0.0f;
+          p.tangentImpulse = 0.0f;
+        }
+        p.rA = V2(0.0f, 0.0f);
+        p.rB = V2(0.0f, 0.0f);
+        p.normalMass = 0.0f;
+        p.tangentMass = 0.0f;
+        p.velocityBias = 0.0f;
+      }
+    }
+  }
+
+  __device__ void csInitVelocityConstraints(int count) {
+    for (int i = 0; i < count; ++i) {
+      VC& c_ = vc[i];
+      const Manifold* manifold = &man[c_.slot];
+      int pA = c_.pA, pB = c_.pB;
+      float radiusA = shapeOf(pA)->radius, radiusB = shapeOf(pB)->radius;
+      float mA = mOf(pA), mB = mOf(pB), iA = iOf(pA), iB = iOf(pB);
+      Vec2 localCenterA = lcOf(pA), localCenterB = lcOf(pB);
+      Vec2 cA = Pc(pA);
+      float aA = Pa(pA);
+      Vec2 vA = Pv(pA);
+      float wA = Pw(pA);
+      Vec2 cB = Pc(pB);
+      float aB = Pa(pB);
+      Vec2 vB = Pv(pB);
+      float wB = Pw(pB);
+      Transform xfA, xfB;
+      xfA.q.Set(aA);
+      xfB.q.Set(aB);
+      xfA.p = cA - Mul(xfA.q, localCenterA);
+      xfB.p = cB - Mul(xfB.q, localCenterB);
+      WorldManifold worldManifold;
+      worldManifold.Initialize(manifold, xfA, radiusA, xfB, radiusB);
+      c_.normal = worldManifold.normal;
+      int pointCount = c_.pointCount;
+      for (int j = 0; j < pointCount; ++j) {
+        VCPoint* vcp = c_.points + j;
+        vcp->rA = worldManifold.points[j] - cA;
+        vcp->rB = worldManifold.points[j] - cB;
+        float rnA = Cross(vcp->rA, c_.normal);
+        float rnB = Cross(vcp->rB, c_.normal);
+        float kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        vcp->normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+        Vec2 tangent = Cross(c_.normal, 1.0f);
+        float rtA = Cross(vcp->rA, tangent);
+        float rtB = Cross(vcp->rB, tangent);
+        float kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+        vcp->tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+        vcp->velocityBias = 0.0f;
+        float vRel = Dot(c_.normal, vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA));
+        if (vRel < -kVelocityThreshold) vcp->velocityBias = -c_.restitution * vRel;
+      }
+      if (c_.pointCount == 2) {
+        VCPoint* vcp1 = c_.points + 0;
+        VCPoint* vcp2 = c_.points + 1;
+        float rn1A = Cross(vcp1->rA, c_.normal);
+        float rn1B = Cross(vcp1->rB, c_.normal);
+        float rn2A = Cross(vcp2->rA, c_.normal);
+        float rn2B = Cross(vcp2->rB, c_.normal);
+        float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
+        float k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+        float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+        const float k_maxConditionNumber = 1000.0f;
+        if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
+          c_.K.ex = V2(k11, k12);
+          c_.K.ey = V2(k12, k22);
+          c_.normalMass = c_.K.GetInverse();
+        } else {
+          c_.pointCount = 1;
+        }
+      }
+    }
+  }
+
+  __device__ void csWarmStart(int count) {
+    for (int i = 0; i < count; ++i) {
+      VC& c_ = vc[i];
+      int pA = c_.pA, pB = c_.pB;
+      float mA = mOf(pA), iA = iOf(pA), mB = mOf(pB), iB = iOf(pB);
+      Vec2 vA = Pv(pA);
+      float wA = Pw(pA);
+      Vec2 vB = Pv(pB);
+      float wB = Pw(pB);
+      Vec2 normal = c_.normal;
+      Vec2 tangent = Cross(normal, 1.0f);
+      for (int j = 0; j < c_.pointCount; ++j) {
+        VCPoint* vcp = c_.points + j;
+        Vec2 P = vcp->normalImpulse * normal + vcp->tangentImpulse * tangent;
+        wA -= iA * Cross(vcp->rA, P);
+        vA -= mA * P;
+        wB += iB * Cross(vcp->rB, P);
+        vB += mB * P;
+      }
+      setVel(pA, vA, wA);
+      setVel(pB, vB, wB);
+    }
+  }
+
+  __device__ void csSolveVelocityConstraints(int count) {
+    for (int i = 0; i < count; ++i) {
+      VC& c_ = vc[i];
+      int pA = c_.pA, pB = c_.pB;
+      float mA = mOf(pA), iA = iOf(pA), mB = mOf(pB), iB = iOf(pB);
+      int pointCount = c_.pointCount;
+      Vec2 vA = Pv(pA);
+      float wA = Pw(pA);
+      Vec2 vB = Pv(pB);
+      float wB = Pw(pB);
+      Vec2 normal = c_.normal;
+      Vec2 tangent = Cross(normal, 1.0f);
+      float friction = c_.friction;
+      for (int j = 0; j < pointCount; ++j) {
+        VCPoint* vcp = c_.points + j;
+        Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+        float vt = Dot(dv, tangent) - 0.0f;
+        float lambda = vcp->tangentMass * (-vt);
+        float maxFriction = friction * vcp->normalImpulse;
+        float newImpulse = Clamp(vcp->tangentImpulse + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - vcp->tangentImpulse;
+        vcp->tangentImpulse = newImpulse;
+        Vec2 P = lambda * tangent;
+        vA -= mA * P;
+        wA -= iA * Cross(vcp->rA, P);
+        vB += mB * P;
+        wB += iB * Cross(vcp->rB, P);
+      }
+      if (pointCount == 1) {
+        VCPoint* vcp = c_.points + 0;
+        Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+        float vn = Dot(dv, normal);
+        float lambda = -vcp->normalMass * (vn - vcp->velocityBias);
+        float newImpulse = Max(vcp->normalImpulse + lambda, 0.0f);
+        lambda = newImpulse - vcp->normalImpulse;
+        vcp->normalImpulse = newImpulse;
+        Vec2 P = lambda * normal;
+        vA -= mA * P;
+        wA -= iA * Cross(vcp->rA, P);
+        vB += mB * P;
+        wB += iB * Cross(vcp->rB, P);
+      } else {
+        VCPoint* cp1 = c_.points + 0;
+        VCPoint* cp2 = c_.points + 1;
+        Vec2 a_ = V2(cp1->normalImpulse, cp2->normalImpulse);
+        Vec2 dv1 = vB + Cross(wB, cp1->rB) - vA - Cross(wA, cp1->rA);
+        Vec2 dv2 = vB + Cross(wB, cp2->rB) - vA - Cross(wA, cp2->rA);
+        float vn1 = Dot(dv1, normal);
+        float vn2 = Dot(dv2, normal);
+        Vec2 b;
+        b.x = vn1 - cp1->velocityBias;
+        b.y = vn2 - cp2->velocityBias;
+        b -= Mul(c_.K, a_);
+        Vec2 x;
+        bool solved = false;
+        // case 1
+        x = -Mul(c_.normalMass, b);
+        if (x.x >= 0.0f && x.y >= 0.0f) solved = true;
+        if (!solved) {  // case 2
+          x.x = -cp1->normalMass * b.x;
+          x.y = 0.0f;
+          vn2 = c_.K.ex.y * x.x + b.y;
+          if (x.x >= 0.0f && vn2 >= 0.0f) solved = true;
+        }
+        if (!solved) {  // case 3
+          x.x = 0.0f;
+          x.y = -cp2->normalMass * b.y;
+          vn1 = c_.K.ey.x * x.y + b.x;
+          if (x.y >= 0.0f && vn1 >= 0.0f) solved = true;
+        }
+        if (!solved) {  // case 4
+          x.x = 0.0f;
+          x.y = 0.0f;
+          vn1 = b.x;
+          vn2 = b.y;
+          if (vn1 >= 0.0f && vn2 >= 0.0f) solved = true;
+        }
+        if (solved) {
+          Vec2 d = x - a_;
+          Vec2 P1 = d.x * normal;
+          Vec2 P2 = d.y * normal;
+          vA -= mA * (P1 + P2);
+          wA -= iA * (Cross(cp1->rA, P1) + Cross(cp2->rA, P2));
+          vB += mB * (P1 + P2);
+          wB += iB * (Cross(cp1->rB, P1) + Cross(cp2->rB, P2));
+          cp1->normalImpulse = x.x;
+          cp2->normalImpulse = x.y;
+        }
+      }
+      setVel(pA, vA, wA);
+      setVel(pB, vB, wB);
+    }
+  }
+
+  __device__ void csStoreImpulses(int count) {
+    for (int i = 0; i < count; ++i) {
+      VC& c_ = vc[i];
+      Manifold& m = man[c_.slot];
+      for (int j = 0; j < c_.pointCount; ++j) {
+        m.points[j].normalImpulse = c_.points[j].normalImpulse;
+        m.points[j].tangentImpulse = c_.points[j].tangentImpulse;
+      }
+    }
+  }
+
+  // b2PositionSolverManifold::Initialize + one b2ContactSolver position iteration (baumgarte/limit differ for TOI)
+  __device__ float csSolvePosition(int count, bool toiMode, int toiBody) {
+    float minSeparation = 0.0f;
+    for (int i = 0; i < count; ++i) {
+      VC& c_ = vc[i];
+      const Manifold& m = man[c_.slot];
+      int pA = c_.pA, pB = c_.pB;
+      Vec2 localCenterA = lcOf(pA), localCenterB = lcOf(pB);
+      float mA = mOf(pA), iA = iOf(pA), mB = mOf(pB), iB = iOf(pB);
+      if (toiMode) {  // only the TOI pair moves (the wall of the pair has zero mass anyway)
+        if (pA != toiBody) {
+          mA = 0.0f;
+          iA = 0.0f;
+        }
+        if (pB != toiBody) {
+          mB = 0.0f;
+          iB = 0.0f;
+        }
+      }
+      float radiusA = shapeOf(pA)->radius, radiusB = shapeOf(pB)->radius;
+      int pointCount = m.pointCount;
+      Vec2 cA = Pc(pA);
+      float aA = Pa(pA);
+      Vec2 cB = Pc(pB);
+      float aB = Pa(pB);
+      for (int j = 0; j < pointCount; ++j) {
+        Transform xfA, xfB;
+        xfA.q.Set(aA);
+        xfB.q.Set(aB);
+        xfA.p = cA - Mul(xfA.q, localCenterA);
+        xfB.p = cB - Mul(xfB.q, localCenterB);
+        Vec2 normal, point;
+        float separation;
+        if (m.type == kManifoldCircles) {
+          Vec2 pointA = Mul(xfA, m.localPoint);
+          Vec2 pointB = Mul(xfB, m.points[0].localPoint);
+          normal = pointB - pointA;
+          Normalize(normal);
+          point = 0.5f * (pointA + pointB);
+          separation = Dot(pointB - pointA, normal) - radiusA - radiusB;
+        } else if (m.type == kManifoldFaceA) {
+          normal = Mul(xfA.q, m.localNormal);
+          Vec2 planePoint = Mul(xfA, m.localPoint);
+          Vec2 clipPoint = Mul(xfB, m.points[j].localPoint);
+          separation = Dot(clipPoint - planePoint, normal) - radiusA - radiusB;
+          point = clipPoint;
+        } else {
+          normal = Mul(xfB.q, m.localNormal);
+          Vec2 planePoint = Mul(xfB, m.localPoint);
+          Vec2 clipPoint = Mul(xfA, m.points[j].localPoint);
+          separation = Dot(clipPoint - planePoint, normal) - radiusA - radiusB;
+          point = clipPoint;
+          normal = -normal;
+        }
+        Vec2 rA = point - cA;
+        Vec2 rB = point - cB;
+        minSeparation = Min(minSeparation, separation);
+        float C = Clamp((toiMode ? kToiBaumgarte : kBaumgarte) * (separation + kLinearSlop), -kMaxLinearCorrection, 0.0f);
+        float rnA = Cross(rA, normal);
+        float rnB = Cross(rB, normal);
+        float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        float impulse = K > 0.0f ? -C / K : 0.0f;
+        Vec2 P = impulse * normal;
+        cA -= mA * P;
+        aA -= iA * Cross(rA, P);
+        cB += mB * P;
+        aB += iB * Cross(rB, P);
+      }
+      setPos(pA, cA, aA);
+      setPos(pB, cB, aB);
+    }
+    return minSeparation;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // b2RevoluteJoint
+  // ------------------------------------------------------------------------------------------------
+  __device__ void jointInit(int j, bool warmStarting, float dtRatio) {
+    const DevJoint& J = S->joints[j];
+    int A = J.bodyA, B = J.bodyB;
+    float aA = pa[A];
+    Vec2 vA = pv[A];
+    float wA = pw[A];
+    float aB = pa[B];
+    Vec2 vB = pv[B];
+    float wB = pw[B];
+    Rot qA = MakeRot(aA), qB = MakeRot(aB);
+    jrA[j] = Mul(qA, J.anchorA - lc[A]);
+    jrB[j] = Mul(qB, J.anchorB - lc[B]);
+    Vec2 rA = jrA[j], rB = jrB[j];
+    float mA = invMass[A], mB = invMass[B];
+    float iA = invI[A], iB = invI[B];
+    bool fixedRotation = (iA + iB == 0.0f);
+    Mat33& M = jmass[j];
+    M.ex.x = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+    M.ey.x = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+    M.ez.x = -rA.y * iA - rB.y * iB;
+    M.ex.y = M.ey.x;
+    M.ey.y = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+    M.ez.y = rA.x * iA + rB.x * iB;
+    M.ex.z = M.ez.x;
+    M.ey.z = M.ez.y;
+    M.ez.z = iA + iB;
+    float motorMass = iA + iB;
+    if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
+    jmotorMass[j] = motorMass;
+    if (fixedRotation) jmotor[j] = 0.0f;
+    if (J.enableLimit && fixedRotation == false) {
+      float jointAngle = aB - aA - jref[j];
+      if (Abs(J.upper - J.lower) < 2.0f * kAngularSlop) {
+        jlimit[j] = kEqualLimits;
+      } else if (jointAngle <= J.lower) {
+        if (jlimit[j] != kAtLowerLimit) jimp[j].z = 0.0f;
+        jlimit[j] = kAtLowerLimit;
+      } else if (jointAngle >= J.upper) {
+        if (jlimit[j] != kAtUpperLimit) jimp[j].z = 0.0f;
+        jlimit[j] = kAtUpperLimit;
+      } else {
+        jlimit[j] = kInactiveLimit;
+        jimp[j].z = 0.0f;
+      }
+    } else {
+      jlimit[j] = kInactiveLimit;
+    }
+    if (warmStarting) {
+      jimp[j] *= dtRatio;
+      jmotor[j] *= dtRatio;
+      Vec2 P = V2(jimp[j].x, jimp[j].y);
+      vA -= mA * P;
+      wA -= iA * (Cross(rA, P) + jmotor[j] + jimp[j].z);
+      vB += mB * P;
+      wB += iB * (Cross(rB, P) + jmotor[j] + jimp[j].z);
+    } else {
+      jimp[j] = Vec3{0.0f, 0.0f, 0.0f};
+      jmotor[j] = 0.0f;
+    }
+    pv[A] = vA;
+    pw[A] = wA;
+    pv[B] = vB;
+    pw[B] = wB;
+  }
+
+  __device__ void jointSolveVelocity(int j, float dt) {
+    const DevJoint& J = S->joints[j];
+    int A = J.bodyA, B = J.bodyB;
+    Vec2 vA = pv[A];
+    float wA = pw[A];
+    Vec2 vB = pv[B];
+    float wB = pw[B];
+    float mA = invMass[A], mB = invMass[B];
+    float iA = invI[A], iB = invI[B];
+    Vec2 rA = jrA[j], rB = jrB[j];
+    const Mat33& M = jmass[j];
+    bool fixedRotation = (iA + iB == 0.0f);
+    int limitState = jlimit[j];
+    if (limitState != kEqualLimits && fixedRotation == false) {  // enableMotor is always true (world_env.py:260)
+      float Cdot = wB - wA - jspeed[j];
+      float impulse = -jmotorMass[j] * Cdot;
+      float oldImpulse = jmotor[j];
+      float maxImpulse = dt * J.maxMotorTorque;
+      jmotor[j] = Clamp(jmotor[j] + impulse, -maxImpulse, maxImpulse);
+      impulse = jmotor[j] - oldImpulse;
+      wA -= iA * impulse;
+      wB += iB * impulse;
+    }
+    if (J.enableLimit && limitState != kInactiveLimit && fixedRotation == false) {
+      Vec2 Cdot1 = vB + Cross(wB, rB) - vA - Cross(wA, rA);
+      float Cdot2 = wB - wA;
+      Vec3 Cdot = Vec3{Cdot1.x, Cdot1.y, Cdot2};
+      Vec3 impulse = -M.Solve33(Cdot);
+      Vec3 acc = jimp[j];
+      if (limitState == kEqualLimits) {
+        acc += impulse;
+      } else if (limitState == kAtLowerLimit) {
+        float newImpulse = acc.z + impulse.z;
+        if (newImpulse < 0.0f) {
+          Vec2 rhs = -Cdot1 + acc.z * V2(M.ez.x, M.ez.y);
+          Vec2 reduced = M.Solve22(rhs);
+          impulse.x = reduced.x;
+          impulse.y = reduced.y;
+          impulse.z = -acc.z;
+          acc.x += reduced.x;
+          acc.y += reduced.y;
+          acc.z = 0.0f;
+        } else {
+          acc += impulse;
+        }
+      } else if (limitState == kAtUpperLimit) {
+        float newImpulse = acc.z + impulse.z;
+        if (newImpulse > 0.0f) {
+          Vec2 rhs = -Cdot1 + acc.z * V2(M.ez.x, M.ez.y);
+          Vec2 reduced = M.Solve22(rhs);
+          impulse.x = reduced.x;
+          impulse.y = reduced.y;
+          impulse.z = -acc.z;
+          acc.x += reduced.x;
+          acc.y += reduced.y;
+          acc.z = 0.0f;
+        } else {
+          acc += impulse;
+        }
+      }
+      jimp[j] = acc;
+      Vec2 P = V2(impulse.x, impulse.y);
+      vA -= mA * P;
+      wA -= iA * (Cross(rA, P) + impulse.z);
+      vB += mB * P;
+      wB += iB * (Cross(rB, P) + impulse.z);
+    } else {
+      Vec2 Cdot = vB + Cross(wB, rB) - vA - Cross(wA, rA);
+      Vec2 impulse = M.Solve22(-Cdot);
+      jimp[j].x += impulse.x;
+      jimp[j].y += impulse.y;
+      vA -= mA * impulse;
+      wA -= iA * Cross(rA, impulse);
+      vB += mB * impulse;
+      wB += iB * Cross(rB, impulse);
+    }
+    pv[A] = vA;
+    pw[A] = wA;
+    pv[B] = vB;
+    pw[B] = wB;
+  }
+
+  __device__ bool jointSolvePosition(int j) {
+    const DevJoint& J = S->joints[j];
+    int A = J.bodyA, B = J.bodyB;
+    Vec2 cA = pc[A];
+    float aA = pa[A];
+    Vec2 cB = pc[B];
+    float aB = pa[B];
+    float mA = invMass[A], mB = invMass[B];
+    float iA = invI[A], iB = invI[B];
+    float angularError = 0.0f;
+    float positionError = 0.0f;
+    bool fixedRotation = (iA + iB == 0.0f);
+    int limitState = jlimit[j];
+    if (J.enableLimit && limitState != kInactiveLimit && fixedRotation == false) {
+      float angle = aB - aA - jref[j];
+      float limitImpulse = 0.0f;
+      if (limitState == kEqualLimits) {
+        float C = Clamp(angle - J.lower, -kMaxAngularCorrection, kMaxAngularCorrection);
+        limitImpulse = -jmotorMass[j] * C;
+        angularError = Abs(C);
+      } else if (limitState == kAtLowerLimit) {
+        float C = angle - J.lower;
+        angularError = -C;
+        C = Clamp(C + kAngularSlop, -kMaxAngularCorrection, 0.0f);
+        limitImpulse = -jmotorMass[j] * C;
+      } else if (limitState == kAtUpperLimit) {
+        float C = angle - J.upper;
+        angularError = C;
+        C = Clamp(C - kAngularSlop, 0.0f, kMaxAngularCorrection);
+        limitImpulse = -jmotorMass[j] * C;
+      }
+      aA -= iA * limitImpulse;
+      aB += iB * limitImpulse;
+    }
+    {
+      Rot qA = MakeRot(aA), qB = MakeRot(aB);
+      Vec2 rA = Mul(qA, J.anchorA - lc[A]);
+      Vec2 rB = Mul(qB, J.anchorB - lc[B]);
+      Vec2 C = cB + rB - cA - rA;
+      positionError = Length(C);
+      Mat22 K;
+      K.ex.x = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
+      K.ex.y = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+      K.ey.x = K.ex.y;
+      K.ey.y = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+      Vec2 impulse = -K.Solve(C);
+      cA -= mA * impulse;
+      aA -= iA * Cross(rA, impulse);
+      cB += mB * impulse;
+      aB += iB * Cross(rB, impulse);
+    }
+    pc[A] = cA;
+    pa[A] = aA;
+    pc[B] = cB;
+    pa[B] = aB;
+    return positionError <= kLinearSlop && angularError <= kAngularSlop;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // b2Island::Solve for the island {bodies in ibmask, contacts ic[0..nic), joints ij[0..nij)}
+  // ------------------------------------------------------------------------------------------------
+  __device__ void integratePositions(uint32_t ibmask, float h) {
+    const int nb = S->nb;
+    for (int i = 0; i < NB; ++i) {
+      if (i >= nb) break;
+      if (!((ibmask >> i) & 1)) continue;
+      Vec2 c_ = pc[i];
+      float a_ = pa[i];
+      Vec2 v_ = pv[i];
+      float w_ = pw[i];
+      Vec2 translation = h * v_;
+      if (Dot(translation, translation) > kMaxTranslationSquared) {
+        float ratio = kMaxTranslation / Length(translation);
+        v_ *= ratio;
+      }
+      float rotation = h * w_;
+      if (rotation * rotation > kMaxRotationSquared) {
+        float ratio = kMaxRotation / Abs(rotation);
+        w_ *= ratio;
+      }
+      c_ += h * v_;
+      a_ += h * w_;
+      pc[i] = c_;
+      pa[i] = a_;
+      pv[i] = v_;
+      pw[i] = w_;
+    }
+  }
+
+  __device__ void islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
+    const int nb = S->nb;
+    Vec2 gravity = S->gravity;
+    for (int i = 0; i < NB; ++i) {
+      if (i >= nb) break;
+      if (!((ibmask >> i) & 1)) continue;
+      Vec2 v_ = v[i];
+      float w_ = w[i];
+      c0[i] = c[i];
+      a0[i] = a[i];
+      v_ += h * (1.0f * gravity + invMass[i] * V2(0.0f, 0.0f));
+      w_ += h * invI[i] * 0.0f;
+      v_ *= 1.0f / (1.0f + h * S->bodies[i].linearDamping);
+      w_ *= 1.0f / (1.0f + h * S->bodies[i].angularDamping);
+      pc[i] = c[i];
+      pa[i] = a[i];
+      pv[i] = v_;
+      pw[i] = w_;
+    }
+    csInit(nic, true, dtRatio);
+    csInitVelocityConstraints(nic);
+    csWarmStart(nic);
+    for (int k = 0; k < nij; ++k) jointInit(ij[k], true, dtRatio);
+    const int velIters = S->velIters;
+    for (int it = 0; it < velIters; ++it) {
+      for (int k = 0; k < nij; ++k) jointSolveVelocity(ij[k], h);
+      csSolveVelocityConstraints(nic);
+    }
+    csStoreImpulses(nic);
+    integratePositions(ibmask, h);
+    bool positionSolved = false;
+    const int posIters = S->posIters;
+    for (int it = 0; it < posIters; ++it) {
+      float minSeparation = csSolvePosition(nic, false, -1);
+      bool contactsOkay = minSeparation >= -3.0f * kLinearSlop;
+      bool jointsOkay = true;
+      for (int k = 0; k < nij; ++k) {
+        bool jointOkay = jointSolvePosition(ij[k]);
+        jointsOkay = jointsOkay && jointOkay;
+      }
+      if (contactsOkay && jointsOkay) {
+        positionSolved = true;
+        break;
+      }
+    }
+    for (int i = 0; i < NB; ++i) {
+      if (i >= nb) break;
+      if (!((ibmask >> i) & 1)) continue;
+      c[i] = pc[i];
+      a[i] = pa[i];
+      v[i] = pv[i];
+      w[i] = pw[i];
+      syncTransform(i);
+    }
+    float minSleepTime = kMaxFloat;
+    const float linTolSqr = kLinearSleepTolerance * kLinearSleepTolerance;
+    const float angTolSqr = kAngularSleepTolerance * kAngularSleepTolerance;
+    for (int i = 0; i < NB; ++i) {
+      if (i >= nb) break;
+      if (!((ibmask >> i) & 1)) continue;
+      if (w[i] * w[i] > angTolSqr || Dot(v[i], v[i]) > linTolSqr) {
+        sleepTime[i] = 0.0f;
+        minSleepTime = 0.0f;
+      } else {
+        sleepTime[i] += h;
+        minSleepTime = Min(minSleepTime, sleepTime[i]);
+      }
+    }
+    if (minSleepTime >= kTimeToSleep && positionSolved) {
+      for (int i = 0; i < NB; ++i) {
+        if (i >= nb) break;
+        if ((ibmask >> i) & 1) sleepBody(i);
+      }
+    }
+  }
+
+  // b2World::Solve
+  __device__ void solve(float h, float dtRatio) {
+    const int nb = S->nb;
+    uint32_t bodyIsland = 0, jointIsland = 0;
+    for (int k = 0; k < nc; ++k) pflags[wl[k]] &= ~PF_ISLAND;
+    int stack[NB + 4];
+    for (int seed = NB - 1; seed >= 0; --seed) {
+      if (seed >= nb) continue;
+      if ((bodyIsland >> seed) & 1) continue;
+      if (!awakeDyn(seed)) continue;
+      uint32_t ibmask = 0, wallIsland = 0;
+      int nic = 0, nij = 0, sp = 0;
+      stack[sp++] = 4 + seed;
+      bodyIsland |= 1u << seed;
+      while (sp > 0) {
+        int p = stack[--sp];
+        if (p < 4) continue;  // static bodies join the island but are not expanded
+        int b = p - 4;
+        ibmask |= 1u << b;
+        wake(p);
+        for (int k = 0; k < nc; ++k) {  // contact-edge list of b == world list filtered by b (same relative order)
+          int s = wl[k];
+          int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+          if (pa_ != p && pb_ != p) continue;
+          uint8_t fl = pflags[s];
+          if (fl & PF_ISLAND) continue;
+          if (!(fl & PF_ENABLED) || !(fl & PF_TOUCHING)) continue;
+          ic[nic++] = (uint8_t)s;
+          pflags[s] = fl | PF_ISLAND;
+          int other = pa_ == p ? pb_ : pa_;
+          if (other < 4) {
+            if ((wallIsland >> other) & 1) continue;
+            wallIsland |= 1u << other;
+            stack[sp++] = other;
+          } else {
+            if ((bodyIsland >> (other - 4)) & 1) continue;
+            bodyIsland |= 1u << (other - 4);
+            stack[sp++] = other;
+          }
+        }
+        const DevBody& db = S->bodies[b];
+        for (int k = 0; k < db.nJoints; ++k) {
+          int j = db.joints[k];
+          if ((jointIsland >> j) & 1) continue;
+          int other = S->joints[j].bodyA == b ? S->joints[j].bodyB : S->joints[j].bodyA;
+          ij[nij++] = (uint8_t)j;
+          jointIsland |= 1u << j;
+          if ((bodyIsland >> other) & 1) continue;
+          bodyIsland |= 1u << other;
+          stack[sp++] = 4 + other;
+        }
+      }
+      islandSolve(ibmask, nic, nij, h, dtRatio);
+    }
+    for (int i = NB - 1; i >= 0; --i) {
+      if (i >= nb) continue;
+      if ((bodyIsland >> i) & 1) synchronizeFixtures(i);
+    }
+    findNewContacts(false);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // b2World::SolveTOI (+ b2Island::SolveTOI).  Without bullets only dynamic-vs-wall contacts are eligible, so a TOI
+  // island is one dynamic body plus the walls it touches at the time of impact.
+  // ------------------------------------------------------------------------------------------------
+  __device__ Sweep sweepOf(int p) const {
+    Sweep sw;
+    if (p < 4) {
+      sw.localCenter = V2(0.0f, 0.0f);
+      sw.c0 = sw.c = V2(0.0f, 0.0f);
+      sw.a0 = sw.a = 0.0f;
+      sw.alpha0 = wallAlpha0[p];
+    } else {
+      int i = p - 4;
+      sw.localCenter = lc[i];
+      sw.c0 = c0[i];
+      sw.c = c[i];
+      sw.a0 = a0[i];
+      sw.a = a[i];
+      sw.alpha0 = alpha0[i];
+    }
+    return sw;
+  }
+  __device__ void advanceBody(int i, float alpha) {  // b2Body::Advance
+    Sweep sw = sweepOf(4 + i);
+    sw.Advance(alpha);
+    c0[i] = sw.c0;
+    a0[i] = sw.a0;
+    alpha0[i] = sw.alpha0;
+    c[i] = c0[i];
+    a[i] = a0[i];
+    q[i].Set(a[i]);
+    xfp[i] = c[i] - Mul(q[i], lc[i]);
+  }
+
+  __device__ void solveTOI(float dt) {
+    const int nb = S->nb;
+    for (int i = 0; i < NB; ++i)
+      if (i < nb) alpha0[i] = 0.0f;
+    for (int k = 0; k < 4; ++k) wallAlpha0[k] = 0.0f;
+    for (int k = 0; k < nc; ++k) {
+      int s = wl[k];
+      pflags[s] &= ~(PF_TOI | PF_ISLAND);
+      toiCount[s] = 0;
+      toi[s] = 1.0f;
+    }
+    for (int guard = 0; guard < 64 * (NP + 1); ++guard) {
+      int minSlot = -1;
+      float minAlpha = 1.0f;
+      for (int k = 0; k < nc; ++k) {
+        int s = wl[k];
+        uint8_t fl = pflags[s];
+        if (!(fl & PF_ENABLED)) continue;
+        if (toiCount[s] > kMaxSubSteps) continue;
+        float alpha = 1.0f;
+        if (fl & PF_TOI) {
+          alpha = toi[s];
+        } else {
+          int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+          if (pa_ >= 4) continue;  // two non-bullet dynamic bodies
+          int b = pb_ - 4;
+          if (!awakeDyn(b)) continue;
+          // put the sweeps onto the same time interval (the wall's alpha0 is part of the state, see b2World::SolveTOI)
+          float alpha0_ = wallAlpha0[pa_];
+          if (wallAlpha0[pa_] < alpha0[b]) {
+            alpha0_ = alpha0[b];
+            wallAlpha0[pa_] = alpha0_;  // wall sweep Advance: c0 = c = 0 stays, alpha0 moves
+          } else if (alpha0[b] < wallAlpha0[pa_]) {
+            alpha0_ = wallAlpha0[pa_];
+            Sweep sw = sweepOf(pb_);
+            sw.Advance(alpha0_);
+            c0[b] = sw.c0;
+            a0[b] = sw.a0;
+            alpha0[b] = sw.alpha0;
+          }
+          DistanceProxy proxyA, proxyB;
+          proxyA.Set(shapeOf(pa_));
+          proxyB.Set(shapeOf(pb_));
+          TOIOutput output;
+          TimeOfImpact(&output, &proxyA, sweepOf(pa_), &proxyB, sweepOf(pb_), 1.0f);
+          float beta = output.t;
+          if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
+          else alpha = 1.0f;
+          toi[s] = alpha;
+          pflags[s] = fl | PF_TOI;
+        }
+        if (alpha < minAlpha) {
+          minSlot = s;
+          minAlpha = alpha;
+        }
+      }
+      if (minSlot < 0 || 1.0f - 10.0f * kEpsilon < minAlpha) break;
+
+      const int wA = S->pairs[minSlot].a;      // wall (fixture A)
+      const int pB = S->pairs[minSlot].b;
+      const int b = pB - 4;
+      // backups
+      float backupWallAlpha = wallAlpha0[wA];
+      Vec2 bc0 = c0[b], bc = c[b];
+      float ba0 = a0[b], ba = a[b], balpha0 = alpha0[b];
+      // bA->Advance(minAlpha) for the wall, bB->Advance(minAlpha)
+      wallAlpha0[wA] = minAlpha;
+      advanceBody(b, minAlpha);
+      updateContact(minSlot);
+      pflags[minSlot] &= ~PF_TOI;
+      ++toiCount[minSlot];
+      if (!(pflags[minSlot] & PF_ENABLED) || !(pflags[minSlot] & PF_TOUCHING)) {
+        pflags[minSlot] &= ~PF_ENABLED;
+        wallAlpha0[wA] = backupWallAlpha;
+        c0[b] = bc0;
+        c[b] = bc;
+        a0[b] = ba0;
+        a[b] = ba;
+        alpha0[b] = balpha0;
+        syncTransform(b);
+        continue;
+      }
+      wake(pB);
+      // build the TOI island: contact list of the dynamic body, static others only
+      uint32_t wallIsland = 1u << wA;
+      int nic = 0;
+      ic[nic++] = (uint8_t)minSlot;
+      pflags[minSlot] |= PF_ISLAND;
+      for (int k = 0; k < nc; ++k) {
+        if (nic == kMaxTOIContacts) break;
+        int s = wl[k];
+        int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+        if (pa_ != pB && pb_ != pB) continue;
+        if (pflags[s] & PF_ISLAND) continue;
+        int other = pa_ == pB ? pb_ : pa_;
+        if (other >= 4) continue;  // only static (no bullets)
+        float backup = wallAlpha0[other];
+        if (!((wallIsland >> other) & 1)) wallAlpha0[other] = minAlpha;  // other->Advance(minAlpha)
+        updateContact(s);
+        if (!(pflags[s] & PF_ENABLED) || !(pflags[s] & PF_TOUCHING)) {
+          wallAlpha0[other] = backup;
+          continue;
+        }
+        pflags[s] |= PF_ISLAND;
+        ic[nic++] = (uint8_t)s;
+        wallIsland |= 1u << other;
+      }
+      // b2Island::SolveTOI
+      float h = (1.0f - minAlpha) * dt;
+      pc[b] = c[b];
+      pa[b] = a[b];
+      pv[b] = v[b];
+      pw[b] = w[b];
+      csInit(nic, false, 1.0f);
+      for (int it = 0; it < 20; ++it) {
+        float minSeparation = csSolvePosition(nic, true, pB);
+        if (minSeparation >= -1.5f * kLinearSlop) break;
+      }
+      c0[b] = pc[b];
+      a0[b] = pa[b];
+      csInitVelocityConstraints(nic);
+      const int velIters = S->velIters;
+      for (int it = 0; it < velIters; ++it) csSolveVelocityConstraints(nic);
+      integratePositions(1u << b, h);
+      c[b] = pc[b];
+      a[b] = pa[b];
+      v[b] = pv[b];
+      w[b] = pw[b];
+      syncTransform(b);
+      // reset island flags, synchronize the broad phase, invalidate the body's contact TOIs
+      synchronizeFixtures(b);
+      for (int k = 0; k < nc; ++k) {
+        int s = wl[k];
+        if (S->pairs[s].a == pB || S->pairs[s].b == pB) pflags[s] &= ~(PF_TOI | PF_ISLAND);
+      }
+      findNewContacts(false);
+    }
+  }
+
+  // b2World::Step
+  __device__ void worldStep() {
+    if (wflags & WF_NEWFIXTURE) {
+      findNewContacts(true);
+      wflags &= ~WF_NEWFIXTURE;
+    }
+    float dt = S->dt;
+    float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
+    float dtRatio = inv_dt0 * dt;
+    collide();
+    solve(dt, dtRatio);
+    solveTOI(dt);
+    inv_dt0 = inv_dt;
+  }
+
+  // action -> joint.motorSpeed (boxLCD/utils.py:117 mapto, world_env.py:441); b2RevoluteJoint::SetMotorSpeed wakes both bodies
+  __device__ void setMotorSpeeds(const float* __restrict__ actions, int N, int e) {
+    const int nj = S->nj, nact = S->nact;
+    for (int j = 0; j < NJ; ++j) {
+      if (j >= nj) break;
+      const DevJoint& J = S->joints[j];
+      if (J.actionIndex < 0) continue;
+      double act = actions ? (double)actions[(size_t)e * nact + J.actionIndex] : 0.0;
+      double m = ((act + 1.0) / 2.0 * (double)(1 - (-1))) + (double)(-1);
+      double cl = m < -1.0 ? -1.0 : (m > 1.0 ? 1.0 : m);
+      jspeed[j] = (float)((double)J.speed * cl);
+      wake(4 + J.bodyA);
+      wake(4 + J.bodyB);
+    }
+  }
+
+  __device__ void checkFault() {
+    const int nb = S->nb;
+    for (int i = 0; i < NB; ++i) {
+      if (i >= nb) break;
+      float t = c[i].x + c[i].y + a[i] + v[i].x + v[i].y + w[i];
+      if (!(t == t) || Abs(t) > 3.0e38f) fault |= FAULT_NAN;
+    }
+  }
+};
+
+}  // namespace blcd
