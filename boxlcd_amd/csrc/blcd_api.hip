@@ -233,7 +233,7 @@ __global__ void faults_kernel(const DevScene* __restrict__ S, const float* __res
   out[e] = (int)(__float_as_uint(st[off]) >> 8);
 }
 
-// canonical dump (same layout as the oracle's b2o_dump)
+// canonical dump (same layout as the parity oracle's dump)
 __global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, float* __restrict__ bodies,
                             float* __restrict__ joints, float* __restrict__ pairs) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,6 +468,7 @@ struct blcd_handle_s {
   size_t words = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> evPool;  // pairs of events, one pair per step launch of a rollout
   float lastMs = 0.0f;
   int lastLaunches = 0;
   // staging
@@ -551,9 +552,14 @@ static int pick_cfg(const DevScene& S) {
   return -1;
 }
 
-static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors) {
+static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors,
+                       hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid((h->N + kBlock - 1) / kBlock), block(kBlock);
-  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  if (!e0) {
+    e0 = h->ev0;
+    e1 = h->ev1;
+  }
+  HIPCHK(hipEventRecord(e0, h->stream));
   int idx = 0;
 #define X(a, b, c)                                                                                              \
   if (h->cfg == idx)                                                                                            \
@@ -563,7 +569,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   BLCD_CONFIGS(X)
 #undef X
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventRecord(e1, h->stream));
   h->lastLaunches += 1;
   return BLCD_OK;
 }
@@ -649,6 +655,7 @@ int blcd_destroy(blcd_handle h) {
   if (h->dScene) (void)hipFree(h->dScene);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t ev : h->evPool) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BLCD_OK;
@@ -724,21 +731,26 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
   if ((rc = out_ptr(h, 1, lcd_out, lcdStep * T, &dLcd))) return rc;
   if ((rc = out_ptr(h, 2, obs_out, obsStep * T * sizeof(float), &dObs))) return rc;
   h->lastLaunches = 0;
-  float total = 0.0f;
+  while ((int)h->evPool.size() < 2 * T) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreate(&ev));
+    h->evPool.push_back(ev);
+  }
   for (int t = 0; t < T; ++t) {
     const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
-    if ((rc = launch_step(h, a, 1, 0, 0))) return rc;
+    if ((rc = launch_step(h, a, 1, 0, 0, h->evPool[2 * t], h->evPool[2 * t + 1]))) return rc;
     if (dLcd || dObs) {
       if ((rc = launch_obs<float>(h, dObs ? (float*)dObs + obsStep * t : nullptr, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr)))
         return rc;
     }
-    // per-launch kernel time: events are re-recorded each step, so read them before the next record
-    HIPCHK(hipEventSynchronize(h->ev1));
-    float ms = 0.0f;
-    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    total += ms;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  float total = 0.0f;  // step-kernel time only: each event pair brackets one step_kernel launch on this stream
+  for (int t = 0; t < T; ++t) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->evPool[2 * t], h->evPool[2 * t + 1]));
+    total += ms;
+  }
   h->lastMs = total;
   if ((rc = out_done(h, 1, lcd_out, lcdStep * T, dLcd))) return rc;
   if ((rc = out_done(h, 2, obs_out, obsStep * T * sizeof(float), dObs))) return rc;

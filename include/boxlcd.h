@@ -156,7 +156,7 @@ void* blcd_stream(blcd_handle h);
  * stream (ms); used by bench.py's roofline block. */
 int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches);
 
-/* ---- parity-test hooks (sub-step granularity + canonical dump; same layout as oracle/b2o_api.h's b2o_dump) ---- */
+/* ---- parity-test hooks (sub-step granularity + canonical dump; same layout as the parity oracle's dump) ---- */
 #define BLCD_BODY_STATE_FLOATS 12 /* cx cy a vx vy w sleepTime awake fat.lo.x fat.lo.y fat.hi.x fat.hi.y */
 #define BLCD_JOINT_STATE_FLOATS 5 /* impulse.x impulse.y impulse.z motorImpulse limitState */
 #define BLCD_PAIR_STATE_FLOATS 18 /* exists touching type pointCount ln.xy lp.xy {p.xy ni ti}x2 id0 id1 */

@@ -1,0 +1,60 @@
+"""Drop-in boundary on the GPU: the gym-style single env and the batched (vector-env-shaped) env."""
+import numpy as np
+import pytest
+import boxlcd_amd as B
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_env_api_like_reference():
+  env = B.envs.Urchin()
+  env.seed(0)
+  obs = env.reset()
+  assert set(obs) == {'full_state', 'proprio', 'lcd'}
+  assert obs['full_state'].dtype == np.float64 and obs['full_state'].shape == (16,) and obs['lcd'].dtype == bool
+  assert obs['lcd'].shape == (16, 32) and obs['proprio'].shape == (16,)
+  assert np.abs(obs['full_state']).max() <= 1.0 + 1e-9
+  for t in range(env.G.ep_len):
+    obs, rew, done, info = env.step(env.action_space.sample())
+  assert rew == 0.0 and done is True and info == {'timeout': True}
+  assert (env.render() == obs['lcd']).all() and (env.lcd_render() == obs['lcd']).all()
+  env.close()
+
+
+def test_reset_with_state_renders_that_state():
+  env = B.envs.LuxoBall()
+  env.seed(1)
+  o1 = env.reset()
+  for _ in range(5):
+    o1 = env.step(np.zeros(3, np.float32))[0]
+  o2 = env.reset(full_state=o1['full_state'])
+  assert np.abs(o2['full_state'] - o1['full_state']).max() < 1e-5
+  assert (o2['lcd'] != o1['lcd']).sum() <= 2        # poses survive a float32 round trip through the normalised state
+  o3 = env.reset(proprio=o1['proprio'])
+  assert np.abs(o3['proprio'] - o1['proprio']).max() < 1e-5
+  env.close()
+
+
+def test_batched_env_shapes_and_torch_zero_copy():
+  import torch
+  n = 512
+  venv = B.BatchedWorldEnv('LuxoBall', n, seed=0)
+  obs = venv.reset()
+  assert obs['full_state'].shape == (n, 20) and obs['full_state'].dtype == np.float32
+  assert obs['lcd'].shape == (n, 16, 24) and obs['lcd'].dtype == bool and obs['proprio'].shape == (n, 16)
+  obs, rew, done, infos = venv.step(venv.sample_actions())
+  assert rew.shape == (n,) and done.shape == (n,) and len(infos) == n and not done.any()
+  # device-resident rollout: actions and outputs are torch tensors on the GPU, no host copies
+  T = 8
+  acts = torch.as_tensor(venv.sample_actions(T)).cuda()
+  lcd = torch.empty((T, n, 16, 24), dtype=torch.uint8, device='cuda')
+  fs = torch.empty((T, n, 20), dtype=torch.float32, device='cuda')
+  h = venv._handle()
+  h.rollout(acts, T, lcd, fs)
+  torch.cuda.synchronize()
+  host_fs, host_lcd = h.get_obs(np.float32)
+  assert (lcd[-1].cpu().numpy() == host_lcd).all() and (fs[-1].cpu().numpy() == host_fs).all()
+  # state -> LCD renderer used by the world models
+  frames = venv.render_states(host_fs[:32].astype(np.float64))
+  assert frames.shape == (32, 16, 24) and (frames != host_lcd[:32].astype(bool)).reshape(32, -1).sum(1).max() <= 3
+  venv.close()

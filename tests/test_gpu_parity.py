@@ -1,0 +1,139 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs, world step by
+world step, bit-exact on every state word (positions, velocities, sleep timers, broad-phase AABBs, manifolds, accumulated
+impulses, joint limit states); LCD frames bit-exact; observations within 1e-6.  Plus size-independent properties at the
+BASELINE sizes where the oracle would be too slow."""
+import numpy as np
+import pytest
+import parity
+import boxlcd_amd as B
+from boxlcd_amd._lib import Handle
+from oracle import pyb2o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name,n,steps', [('Dropbox', 256, 60), ('Bounce', 256, 200), ('Object2', 256, 200),
+                                          ('Urchin', 128, 200), ('LuxoBall', 128, 200)])
+def test_baseline_configs_bit_exact_per_world_step(name, n, steps):
+  cnt, msgs = parity.run_substep_parity(name, n, steps, seed=11)
+  assert cnt == steps * 3 and not msgs, msgs[:5]
+
+
+@pytest.mark.parametrize('name', ['Bounce2', 'Object3', 'Luxo', 'UrchinCube', 'LuxoCube', 'UrchinBall', 'UrchinBalls',
+                                  'LuxoCubes', 'Crab', 'CrabCube', 'SpiderCube'])
+def test_rest_of_catalogue_bit_exact(name):
+  cnt, msgs = parity.run_substep_parity(name, 32, 60, seed=5)
+  assert not msgs, msgs[:5]
+
+
+def test_device_sincos_equals_oracle():
+  rng = np.random.RandomState(0)
+  x = np.concatenate([rng.uniform(-130, 130, 1 << 20), rng.uniform(-1e-2, 1e-2, 4096), rng.uniform(-1e6, 1e6, 4096),
+                      [0.0, -0.0, 0.75, 0.7853982, 119.99, 120.0, 1e9]]).astype(np.float32)
+  from boxlcd_amd import _lib
+  s, c = np.zeros_like(x), np.zeros_like(x)
+  _lib._check(_lib.load().blcd_debug_sincos(_lib._ptr(x), x.size, _lib._ptr(s), _lib._ptr(c), 0))
+  so, co = pyb2o.sincos(x)
+  assert (s == so).all() and (c == co).all()
+
+
+def test_mass_data_equals_oracle():
+  from boxlcd_amd import _lib
+  for name in ['Dropbox', 'Bounce', 'LuxoBall', 'Crab']:
+    d = getattr(B.envs, name)().scene.desc
+    for sh in range(d.n_shapes):
+      out = np.zeros(24, np.float32)
+      _lib._check(_lib.load().blcd_debug_mass_data(d, sh, 0.37, _lib._ptr(out)))
+      assert (out == pyb2o.mass_data(d, sh, 0.37)).all(), (name, sh)
+
+
+@pytest.mark.parametrize('name,variant', [('Urchin', 0), ('Urchin', 1), ('LuxoBall', 1), ('Crab', 1), ('Object2', 0)])
+def test_render_poses_equals_oracle_and_pillow(name, variant):
+  env = B.BatchedWorldEnv(name, 1, raster_variant=variant)
+  g = np.load('tests/golden/pillow_render.npz')
+  poses, sel = g[name + '_poses'], g[name + '_sel']
+  h = Handle(env.scene.desc, 1, 0)
+  got = h.render_poses(poses, sel)
+  assert (got == pyb2o.render_poses(env.scene.desc, poses, sel)).all()
+  if variant == 1:
+    exp = np.unpackbits(g[name + '_frames'], axis=-1, bitorder='little')[..., :env.scene.desc.lcd_w]
+    assert (got == exp).all()
+  h.close()
+
+
+def test_gif_sequences_on_device():
+  """The reference's published Dropbox/Bounce LCD sequences, reproduced by the HIP path itself."""
+  gifs = np.load('tests/golden/gif_lcd_frames.npz')
+  for name, pose, T in [('Dropbox', [1.66, 4.015, 1.315], 26), ('Bounce', [1.55, 4.17, 0.0], 50)]:
+    env = getattr(B.envs, name)()
+    h = Handle(env.scene.desc, 1, 0)
+    h.reset(None, np.array([[pose]], np.float32), None)
+    lcd = np.zeros((T, 1, 16, 16), np.uint8)
+    h.rollout(None, T, lcd_out=lcd)
+    exp = np.unpackbits(gifs[name], axis=-1)[:, :, :16]
+    assert (lcd[:, 0] == exp).all(), name
+    h.close()
+
+
+def test_full_size_properties_bounce_100k():
+  """BASELINE configs[1] size: determinism, shard-invariance, snapshot/restore, and physical sanity (no oracle)."""
+  n, T = 100_000, 60
+  env = B.BatchedWorldEnv('Bounce', n, seed=1)
+  poses, sel = env.sample_initial(n)
+  h = Handle(env.scene.desc, n, 0)
+  h.reset(None, poses, sel)
+  h.step(None, 20)
+  snap = h.get_state()
+  h.step(None, T - 20)
+  b1 = h.debug_dump()[0]
+  _, lcd1 = h.get_obs(None)
+  assert np.isfinite(b1).all() and not h.faults().any()
+  assert (b1[:, 0, 1] > 0.45).all() and (b1[:, 0, 1] < 4.6).all() and (b1[:, 0, 0] > 0.45).all() and (b1[:, 0, 0] < 4.55).all()
+  assert (lcd1.reshape(n, -1).min(1) == 0).all()                       # every ball is visible
+  assert np.all((16 * 16 - lcd1.reshape(n, -1).sum(1)) <= 25)         # r=0.5 ball covers at most a 5x5 pattern
+  # restore + continue == uninterrupted
+  h.set_state(snap)
+  h.step(None, T - 20)
+  assert (h.debug_dump()[0] == b1).all()
+  h.close()
+  # two half-size handles (the multi-GPU sharding unit) == one full handle
+  half = n // 2
+  for lo, hi in [(0, half), (half, n)]:
+    hh = Handle(env.scene.desc, hi - lo, 0)
+    hh.reset(None, poses[lo:hi], sel[lo:hi])
+    hh.step(None, T)
+    assert (hh.debug_dump()[0] == b1[lo:hi]).all()
+    hh.close()
+  # a sample of the full-size batch against the oracle
+  idx = np.random.RandomState(0).choice(n, 64, replace=False)
+  _, _, olcd, ost = pyb2o.rollout(env.scene.desc, poses[idx], sel[idx], None, T, threads=8)
+  assert (ost == b1[idx]).all() and (olcd == lcd1[idx]).all()
+
+
+def test_partial_reset_and_set_poses():
+  n = 64
+  env = B.BatchedWorldEnv('Object2', n, seed=4)
+  poses, sel = env.sample_initial(n)
+  h = Handle(env.scene.desc, n, 0)
+  h.reset(None, poses, sel)
+  h.step(None, 15)
+  before = h.debug_dump()[0].copy()
+  idxs = np.array([3, 17, 40], np.int32)
+  h.reset(idxs, poses[idxs], sel[idxs])
+  after = h.debug_dump()[0]
+  keep = np.setdiff1d(np.arange(n), idxs)
+  assert (after[keep] == before[keep]).all()
+  oras = []
+  for e in idxs:
+    o = pyb2o.OracleEnv(env.scene.desc); o.reset(poses[e], sel[e]); oras.append(o)
+  assert all((after[e] == o.dump()[0]).all() for e, o in zip(idxs, oras))
+  # SetTransform path: poses/LCD equal the oracle's (contact order may differ by design)
+  newp = poses[idxs].copy(); newp[..., 0] = 2.5; newp[:, 0, 1] = 1.0; newp[:, 1, 1] = 3.0; newp[..., 2] = 0.3
+  h.set_poses(idxs, newp, None)
+  for o, p in zip(oras, newp):
+    o.set_poses(p)
+  _, lcd = h.get_obs(None)
+  d = h.debug_dump()[0]
+  for e, o in zip(idxs, oras):
+    assert (lcd[e] == o.render()).all() and (d[e][:, :6] == o.dump()[0][:, :6]).all()
+  h.close()

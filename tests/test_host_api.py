@@ -1,0 +1,151 @@
+"""Host-side logic (no GPU): env catalogue, observation/action tables, spaces, sampling, scene lowering, C-ABI surface."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+import boxlcd_amd as B
+from boxlcd_amd import utils
+
+
+def test_env_map_matches_reference_catalogue():
+  names = {'Dropbox', 'Bounce', 'Bounce2', 'Object2', 'Object3', 'Urchin', 'Luxo', 'UrchinCube', 'LuxoCube', 'UrchinBall',
+           'LuxoBall', 'UrchinBalls', 'LuxoBalls', 'UrchinCubes', 'LuxoCubes', 'Crab', 'CrabCube', 'SpiderCube'}
+  assert set(B.env_map) == names                       # reference boxLCD/envs.py:17-137
+  assert B.ENV_DG.fps == 10 and B.ENV_DG.lcd_base == 16 and B.ENV_DG.wh_ratio == 2.0
+
+
+def test_obs_keys_sorted_and_sizes():
+  e = B.envs.LuxoBall()
+  assert e.obs_keys == sorted(e.obs_keys) and e.obs_size == 20 and e.act_size == 3
+  assert e.obs_keys[:4] == ['luxo0:lfoot:cos', 'luxo0:lfoot:sin', 'luxo0:lfoot:x:p', 'luxo0:lfoot:y:p']
+  assert e.pobs_keys == [k for k in e.obs_keys if not k.startswith('object')] and e.pobs_size == 16
+  assert e.WIDTH == 7 and e.observation_space.spaces['lcd'].shape == (16, 24)      # int(1.5*5) = 7
+  d = B.envs.Dropbox()
+  assert d.obs_keys == ['object0:cos', 'object0:sin', 'object0:x:p', 'object0:y:p'] and d.act_keys == ['dummy']
+  assert d.observation_space.spaces['proprio'].shape == (1,) and d.G.ep_len == 25
+  u = B.envs.Urchin()
+  assert u.act_keys == ['urchin0:aleg:speed', 'urchin0:bleg:speed', 'urchin0:cleg:speed'] and u.obs_size == 16
+  assert u.observation_space.spaces['lcd'].shape == (16, 32) and u.action_space.shape == (3,)
+  c = B.envs.Crab()
+  assert c.scene.desc.n_bodies == 17 and c.scene.desc.n_joints == 16 and c.act_size == 12   # 4 fixed claw tips
+  with pytest.raises(NotImplementedError):
+    B.envs.Urchin({'use_speed': 0})                    # the reference's non-default branches are broken (App. E)
+
+
+def test_G_overrides_and_namespace():
+  import argparse
+  e = B.envs.Bounce({'ep_len': 7})
+  assert e.G.ep_len == 7 and e.G.wh_ratio == 1.0
+  e = B.envs.Bounce(argparse.Namespace(fps=30))
+  assert e.scene.desc.substeps == 1 and abs(e.scene.desc.dt - np.float32(1 / 30)) < 1e-9
+
+
+def test_mapto_rmapto_roundtrip_and_namedarray():
+  lo_hi = utils.A[0, 7]
+  x = np.linspace(-1, 1, 11)
+  assert np.allclose(utils.rmapto(utils.mapto(x, lo_hi), lo_hi), x)
+  info = {'a:x:p': utils.A[0, 10], 'a:cos': utils.A[-1, 1]}
+  na = utils.NamedArray(np.zeros(2), info)
+  na['a:x:p'] = 7.5
+  assert na.arr[0] == 0.5 and na['a:x:p'] == 7.5 and na('a:cos') == 0.0
+  na['a:x:p', 'a:cos'] = np.array([10.0, -1.0])
+  assert (na.arr == [1.0, -1.0]).all() and (na[['a:x:p', 'a:cos']] == [10.0, -1.0]).all()
+
+
+def test_gym_compatible_seeding_and_sampling_ranges():
+  e1, e2 = B.envs.Object2(), B.envs.Object2()
+  e1.seed(3); e2.seed(3)
+  p1, _ = e1._sample_poses(lambda lo, hi: np.array([e1.np_random.uniform(lo, hi)]), 1)
+  p2, _ = e2._sample_poses(lambda lo, hi: np.array([e2.np_random.uniform(lo, hi)]), 1)
+  assert (p1 == p2).all()
+  # known value of gym 0.17.3's seeding.np_random(0): RandomState seeded with sha512('0')[:8] as uint32 list
+  from boxlcd_amd.world_env import np_random
+  rng, s = np_random(0)
+  ref = np.random.RandomState(); 
+  import hashlib, struct
+  h = hashlib.sha512(b'0').digest()[:8] + b'\0' * 4
+  big = sum(v << (32 * i) for i, v in enumerate(struct.unpack('3I', h)))
+  ints = []
+  while big > 0:
+    big, m = divmod(big, 2**32); ints.append(m)
+  ref.seed(ints)
+  assert rng.uniform() == ref.uniform() and s == 0
+  be = B.BatchedWorldEnv('Urchin', 500, seed=1)
+  poses, sel = be.sample_initial(500)
+  assert poses.shape == (500, 4, 3) and poses.dtype == np.float32
+  assert poses[:, 0, 0].min() >= 1.25 - 1e-5 and poses[:, 0, 0].max() <= 8.75 + 1e-5 and np.allclose(poses[:, 0, 1], 1.25)
+  # anchors coincide: leg position = root + R(leg)*(0,-0.6667)
+  legs = poses[:, 1:, :]
+  exp = poses[:, :1, :2] - np.stack([-np.sin(legs[..., 2]), np.cos(legs[..., 2])], -1) * (40 / 30.0 / 2)
+  assert np.abs(legs[..., :2] - exp).max() < 1e-5
+  bo = B.BatchedWorldEnv('Object2', 2000, seed=2)
+  poses, sel = bo.sample_initial(2000)
+  assert set(np.unique(sel)) == {0, 1} and poses[..., :2].min() >= 0.5 - 1e-6 and poses[..., :2].max() <= 4.5 + 1e-6
+
+
+def test_state_to_poses_inverts_obs_normalisation():
+  e = B.BatchedWorldEnv('LuxoBall', 3)
+  fs = np.zeros((3, e.obs_size))
+  na = utils.NamedArray(fs, e.obs_info)
+  na['object0:x:p'] = 3.5; na['object0:y:p'] = 1.0; na['object0:cos'] = np.cos(0.7); na['object0:sin'] = np.sin(0.7)
+  poses = e._state_to_poses(fs)
+  i = e.scene.body_index['object0']
+  assert np.allclose(poses[:, i], [3.5, 1.0, 0.7], atol=1e-6)
+
+
+def test_scene_lowering_invariants():
+  e = B.envs.LuxoBall()
+  d = e.scene.desc
+  assert (d.n_bodies, d.n_joints, d.n_obs, d.n_act) == (5, 3, 20, 3)
+  assert [b.name for b in e.scene.bodies] == ['luxo0:root', 'luxo0:lhip', 'luxo0:lknee', 'luxo0:lfoot', 'object0']
+  assert d.bodies[0].density == np.float32(0.1) and d.bodies[1].density == 1.0 and d.bodies[4].density == np.float32(0.2)
+  assert d.bodies[0].mask_bits == 0x011 and d.bodies[4].category_bits == 0x0110 and d.bodies[4].mask_bits == 0xFFFF
+  assert (d.joints[1].body_a, d.joints[1].body_b) == (1, 2) and d.joints[0].enable_limit == 1
+  kinds = [d.obs[i].kind for i in range(d.n_obs)]
+  assert kinds[:4] == [4, 5, 0, 1] and kinds[12:16] == [2, 3, 0, 1]      # links use transform.angle, root uses body.angle
+  o2 = B.envs.Object2().scene.desc
+  assert o2.bodies[0].n_choices == 2 and o2.shapes[o2.bodies[0].shape[0]].type == 0 and o2.shapes[o2.bodies[0].shape[1]].is_box == 1
+
+
+def test_header_symbols_exported_by_library():
+  """Every function include/boxlcd.h declares is exported by libboxlcd_hip.so and bound by the ctypes layer (no compute)."""
+  from boxlcd_amd import _lib
+  hdr = open('include/boxlcd.h').read()
+  declared = set(re.findall(r'\b(blcd_[a-z_0-9]+)\s*\(', hdr))
+  assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+  if not os.path.exists(_lib.LIB_PATH):
+    pytest.skip('libboxlcd_hip.so not built (run __graft_entry__.build())')
+  lib = ctypes.CDLL(_lib.LIB_PATH)
+  for name in declared:
+    assert hasattr(lib, name), name
+  lib.blcd_version.restype = ctypes.c_int
+  assert lib.blcd_version() == 100
+
+
+def test_scene_struct_layout_matches_c_header():
+  from boxlcd_amd.scene import SceneDesc, ShapeDef, BodyDef, JointDef, ObsDef
+  assert ctypes.sizeof(ShapeDef) == 16 + 64 and ctypes.sizeof(BodyDef) == 48 and ctypes.sizeof(JointDef) == 48
+  assert ctypes.sizeof(ObsDef) == 16
+  assert ctypes.sizeof(SceneDesc) == 64 + 24 * 80 + 20 * 48 + 20 * 48 + 96 * 16
+
+
+def test_no_gpu_means_loud_failure():
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  from boxlcd_amd import _lib
+  if not os.path.exists(_lib.LIB_PATH):
+    with pytest.raises(RuntimeError):
+      B.envs.Dropbox().reset()
+  else:
+    with pytest.raises(RuntimeError, match='no HIP device|hip'):
+      B.envs.Dropbox().reset()
+
+
+def test_product_never_imports_oracle():
+  import glob
+  for path in glob.glob('boxlcd_amd/**/*', recursive=True):
+    if os.path.isfile(path) and path.endswith(('.py', '.h', '.hip', '.cpp')):
+      txt = open(path, errors='ignore').read()
+      assert 'b2o_' not in txt and 'pyb2o' not in txt and 'oracle/' not in txt.replace('the parity oracle', ''), path

@@ -1,0 +1,129 @@
+"""CPU oracle pinned against (1) the reference's published GIF frames (tests/golden/gif_lcd_frames.npz, decoded from
+/root/reference/assets/envs/*.gif by tools/gen_gif_fixtures.py), (2) analytic known answers, (3) glibc for sincosf."""
+import numpy as np
+import pytest
+import boxlcd_amd as B
+
+
+def _gif(name, w):
+  return np.unpackbits(np.load('tests/golden/gif_lcd_frames.npz')[name], axis=-1)[:, :, :w].astype(np.uint8)
+
+
+def _env(oracle, name, pose, variant=0):
+  env = getattr(B.envs, name)(raster_variant=variant)
+  o = oracle.OracleEnv(env.scene.desc)
+  o.reset(np.asarray(pose, np.float32))
+  return env, o
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_dropbox_gif_all_26_frames(oracle, variant):
+  """Reference output pin: from the fitted start pose (tools/fit_gif_dropbox.py) the oracle reproduces every LCD frame of
+  assets/envs/Dropbox.gif: free fall, TOI landing on a corner, tumble, frictional slide, rest, sleep."""
+  gif = _gif('Dropbox', 16)
+  _, o = _env(oracle, 'Dropbox', [[1.66, 4.015, 1.315]], variant)
+  for t in range(26):
+    o.step(np.zeros(1, np.float32))
+    assert (o.render() == gif[t]).all(), f'frame {t}'
+
+
+def test_bounce_gif_all_50_frames(oracle):
+  """Reference output pin: assets/envs/Bounce.gif, four bounces with restitution 0.8 resolved by the TOI solver."""
+  gif = _gif('Bounce', 16)
+  _, o = _env(oracle, 'Bounce', [[1.55, 4.17, 0.0]])
+  for t in range(50):
+    o.step(np.zeros(1, np.float32))
+    assert (o.render() == gif[t]).all(), f'frame {t}'
+
+
+def test_free_fall_increments(oracle):
+  """Semi-implicit Euler, 3 sub-steps of 1/30 s: env-step k moves by -(g/900)(9k-3)."""
+  _, o = _env(oracle, 'Dropbox', [[2.5, 3.6, 0.3]])
+  y = [3.6]
+  for k in range(1, 5):
+    o.step(np.zeros(1, np.float32))
+    y.append(float(o.dump()[0][0, 1]))
+    assert abs((y[-1] - y[-2]) + (9.81 / 900.0) * (9 * k - 3)) < 2e-6
+
+
+def test_box_rest_height_and_sleep(oracle):
+  _, o = _env(oracle, 'Dropbox', [[2.5, 1.5, 0.0]])
+  for _ in range(40):
+    o.step(np.zeros(1, np.float32))
+  b = o.dump()[0][0]
+  assert abs(b[1] - (0.7 + 0.015)) < 2e-3          # half size + 2*polygonRadius - linearSlop
+  assert b[7] == 0.0 and b[3] == 0.0 and b[4] == 0.0  # asleep, velocities zeroed
+  assert o.render()[11:16, :].min() == 0
+
+
+def test_bounce_apex_ratio(oracle):
+  """restitution mixes as max(0.8, 0) -> apex heights above rest shrink by 0.8^2 per bounce."""
+  _, o = _env(oracle, 'Bounce', [[2.5, 4.0, 0.0]])
+  ys = []
+  for _ in range(120):
+    o.step(np.zeros(1, np.float32))
+    ys.append(float(o.dump()[0][0, 1]))
+  ys = np.array(ys)
+  apex = [ys[i] for i in range(1, len(ys) - 1) if ys[i] >= ys[i - 1] and ys[i] > ys[i + 1] and ys[i] > 0.8]
+  rest = 0.5 + 0.01
+  ratios = [(apex[i + 1] - rest) / (apex[i] - rest) for i in range(min(2, len(apex) - 1))]
+  assert len(ratios) >= 1 and all(abs(r - 0.64) < 0.08 for r in ratios), (apex, ratios)
+
+
+def test_urchin_limits_and_motors(oracle):
+  env = B.envs.Urchin()
+  benv = B.BatchedWorldEnv('Urchin', 1, seed=3)
+  poses, sel = benv.sample_initial(1)
+  o = oracle.OracleEnv(env.scene.desc)
+  o.reset(poses[0], sel[0])
+  for t in range(60):
+    o.step(np.array([1.0, -1.0, 1.0], np.float32))
+  b, j, p = o.dump()
+  assert np.isfinite(b).all() and np.isfinite(j).all()
+  assert (b[:, 7] == 1.0).all()                      # SetMotorSpeed keeps the robot awake
+  # joint angle within limits +- slack: aB - aA - ref in [-1, 1]
+  ref = poses[0, 1:, 2] - poses[0, 0, 2]
+  ang = b[1:, 2] - b[0, 2] - ref
+  assert (ang > -1.5).all() and (ang < 1.5).all(), ang   # soft limits under a 150 N m motor
+  assert set(j[:, 4].astype(int).tolist()) <= {0, 1, 2}
+
+
+def test_mass_data_known_answers(oracle):
+  env = B.envs.Dropbox()
+  m = oracle.mass_data(env.scene.desc, 0, 0.1)
+  assert abs(m[0] - 0.1 * 1.4 * 1.4) < 1e-6          # box mass = rho * (2h)^2
+  assert abs(m[3] - m[0] * (1.4**2 + 1.4**2) / 12.0) < 1e-6
+  env = B.envs.Bounce()
+  m = oracle.mass_data(env.scene.desc, 0, 0.1)
+  assert abs(m[0] - 0.1 * np.pi * 0.25) < 1e-6 and abs(m[3] - m[0] * 0.125) < 1e-6
+  env = B.envs.Luxo()
+  m = oracle.mass_data(env.scene.desc, 0, 0.1)        # luxo root: Set() hull is CCW from the right-most lowest vertex
+  n = int(m[4]); v = m[5:5 + 2 * n].reshape(n, 2)
+  assert n == 4 and v[0, 0] == v[:, 0].max() and v[0, 1] == v[v[:, 0] == v[:, 0].max(), 1].min()
+  area2 = sum(v[i, 0] * v[(i + 1) % n, 1] - v[(i + 1) % n, 0] * v[i, 1] for i in range(n))
+  assert area2 > 0 and abs(m[0] - 0.1 * area2 / 2) < 1e-6 and abs(m[1]) > 1e-3   # non-zero centroid
+
+
+def test_sincos_matches_glibc(oracle):
+  """The restated sincosf equals this container's glibc on all but ~1e-8 of inputs (glibc's FMA ifunc variant)."""
+  rng = np.random.RandomState(0)
+  x = np.concatenate([rng.uniform(-130, 130, 2_000_000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, 0.75, 119.99, 120.0, 1e5, -3e7]]).astype(np.float32)
+  s, c = oracle.sincos(x)
+  import ctypes, ctypes.util
+  libm = ctypes.CDLL(ctypes.util.find_library('m'))
+  libm.sinf.restype = ctypes.c_float; libm.sinf.argtypes = [ctypes.c_float]
+  libm.cosf.restype = ctypes.c_float; libm.cosf.argtypes = [ctypes.c_float]
+  idx = rng.randint(0, len(x), 20000).tolist() + list(range(len(x) - 1007, len(x)))
+  bad = sum((libm.sinf(float(x[i])) != s[i]) or (libm.cosf(float(x[i])) != c[i]) for i in idx)
+  assert bad <= 1
+  # and agrees with float64 numpy to float32 rounding everywhere
+  assert np.abs(s - np.sin(x.astype(np.float64))).max() < 6e-8 and np.abs(c - np.cos(x.astype(np.float64))).max() < 6e-8
+
+
+def test_oracle_is_deterministic_and_threaded_rollout_matches(oracle):
+  benv = B.BatchedWorldEnv('Object2', 24, seed=5)
+  poses, sel = benv.sample_initial(24)
+  d = benv.scene.desc
+  _, o1, l1, s1 = oracle.rollout(d, poses, sel, None, 30, threads=1)
+  _, o2, l2, s2 = oracle.rollout(d, poses, sel, None, 30, threads=4)
+  assert (o1 == o2).all() and (l1 == l2).all() and (s1 == s2).all()
