@@ -601,7 +601,11 @@ struct Env {
     }
   }
 
-  __device__ void csSolveVelocityConstraints(int count) {
+  // Returns true iff some constraint applied a non-zero impulse in this sweep.  A sweep is a deterministic function of
+  // (velocities, accumulated impulses); Box2D applies lambda = clamp(acc + d) - acc, so "no accumulator moved" means
+  // every applied impulse was exactly zero and the state is a fixed point: all remaining sweeps are no-ops.
+  __device__ bool csSolveVelocityConstraints(int count) {
+    bool changed = false;
     for (int i = 0; i < count; ++i) {
       VC& c_ = vc[i];
       int pA = c_.pA, pB = c_.pB;
@@ -623,6 +627,7 @@ struct Env {
         float newImpulse = Clamp(vcp->tangentImpulse + lambda, -maxFriction, maxFriction);
         lambda = newImpulse - vcp->tangentImpulse;
         vcp->tangentImpulse = newImpulse;
+        changed = changed || (lambda != 0.0f);
         Vec2 P = lambda * tangent;
         vA -= mA * P;
         wA -= iA * Cross(vcp->rA, P);
@@ -637,6 +642,7 @@ struct Env {
         float newImpulse = Max(vcp->normalImpulse + lambda, 0.0f);
         lambda = newImpulse - vcp->normalImpulse;
         vcp->normalImpulse = newImpulse;
+        changed = changed || (lambda != 0.0f);
         Vec2 P = lambda * normal;
         vA -= mA * P;
         wA -= iA * Cross(vcp->rA, P);
@@ -680,6 +686,7 @@ struct Env {
         }
         if (solved) {
           Vec2 d = x - a_;
+          changed = changed || (d.x != 0.0f) || (d.y != 0.0f);
           Vec2 P1 = d.x * normal;
           Vec2 P2 = d.y * normal;
           vA -= mA * (P1 + P2);
@@ -693,6 +700,7 @@ struct Env {
       setVel(pA, vA, wA);
       setVel(pB, vB, wB);
     }
+    return changed;
   }
 
   __device__ void csStoreImpulses(int count) {
@@ -848,7 +856,8 @@ struct Env {
     pw[B] = wB;
   }
 
-  __device__ void jointSolveVelocity(int j, float dt) {
+  __device__ bool jointSolveVelocity(int j, float dt) {
+    bool changed = false;
     const DevJoint& J = S->joints[j];
     int A = J.bodyA, B = J.bodyB;
     Vec2 vA = pv[A];
@@ -868,6 +877,7 @@ struct Env {
       float maxImpulse = dt * J.maxMotorTorque;
       jmotor[j] = Clamp(jmotor[j] + impulse, -maxImpulse, maxImpulse);
       impulse = jmotor[j] - oldImpulse;
+      changed = changed || (impulse != 0.0f);
       wA -= iA * impulse;
       wB += iB * impulse;
     }
@@ -908,6 +918,8 @@ struct Env {
           acc += impulse;
         }
       }
+      changed = changed || (impulse.x != 0.0f) || (impulse.y != 0.0f) || (impulse.z != 0.0f) || (acc.x != jimp[j].x) ||
+                (acc.y != jimp[j].y) || (acc.z != jimp[j].z);
       jimp[j] = acc;
       Vec2 P = V2(impulse.x, impulse.y);
       vA -= mA * P;
@@ -917,6 +929,7 @@ struct Env {
     } else {
       Vec2 Cdot = vB + Cross(wB, rB) - vA - Cross(wA, rA);
       Vec2 impulse = M.Solve22(-Cdot);
+      changed = changed || (impulse.x != 0.0f) || (impulse.y != 0.0f);
       jimp[j].x += impulse.x;
       jimp[j].y += impulse.y;
       vA -= mA * impulse;
@@ -928,6 +941,7 @@ struct Env {
     pw[A] = wA;
     pv[B] = vB;
     pw[B] = wB;
+    return changed;
   }
 
   __device__ bool jointSolvePosition(int j) {
@@ -1044,8 +1058,10 @@ struct Env {
     for (int k = 0; k < nij; ++k) jointInit(ij[k], true, dtRatio);
     const int velIters = S->velIters;
     for (int it = 0; it < velIters; ++it) {
-      for (int k = 0; k < nij; ++k) jointSolveVelocity(ij[k], h);
-      csSolveVelocityConstraints(nic);
+      bool changed = false;
+      for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
+      changed = csSolveVelocityConstraints(nic) || changed;
+      if (!changed) break;  // bitwise fixed point: the remaining sweeps cannot change anything
     }
     csStoreImpulses(nic);
     integratePositions(ibmask, h);
@@ -1312,7 +1328,8 @@ struct Env {
       a0[b] = pa[b];
       csInitVelocityConstraints(nic);
       const int velIters = S->velIters;
-      for (int it = 0; it < velIters; ++it) csSolveVelocityConstraints(nic);
+      for (int it = 0; it < velIters; ++it)
+        if (!csSolveVelocityConstraints(nic)) break;
       integratePositions(1u << b, h);
       c[b] = pc[b];
       a[b] = pa[b];

@@ -86,6 +86,9 @@ int32_t b2o_num_pairs(b2o_env* e);                         /* canonical pair-slo
 void b2o_pair_table(b2o_env* e, int32_t* pairs);           /* [n][2] proxy ids (0..3 walls, 4.. bodies) */
 void b2o_dump(b2o_env* e, float* bodies, float* joints, float* pairs);
 void b2o_stats(b2o_env* e, int64_t* out6);
+void b2o_track_sweeps(b2o_env* e, int32_t on);   /* diagnostic: histogram of the sweep at which velocities reach a fixed point */
+void b2o_sweep_hist(b2o_env* e, int64_t* out182);
+void b2o_period_hist(b2o_env* e, int64_t* out36);
 int32_t b2o_contact_order(b2o_env* e, int32_t* out_pairs, int32_t cap); /* world contact list, newest first, as pair-slot ids */
 
 /* stateless helpers */

@@ -239,6 +239,15 @@ void b2o_dump(b2o_env* e, float* bodies, float* joints, float* pairs) {
     }
 }
 
+void b2o_track_sweeps(b2o_env* e, int32_t on) { e->world.stats.trackSweeps = on != 0; }
+void b2o_sweep_hist(b2o_env* e, int64_t* out182) {
+  for (int i = 0; i < 182; ++i) out182[i] = e->world.stats.sweepHist[i];
+}
+void b2o_period_hist(b2o_env* e, int64_t* out36) {
+  for (int i = 0; i < 34; ++i) out36[i] = e->world.stats.periodHist[i];
+  out36[34] = e->world.stats.cycleAtSum;
+  out36[35] = e->world.stats.cycleCount;
+}
 void b2o_stats(b2o_env* e, int64_t* out6) {
   const Stats& s = e->world.stats;
   out6[0] = s.steps; out6[1] = s.toiEvents; out6[2] = s.toiCalls; out6[3] = s.islands; out6[4] = s.contactsCreated;

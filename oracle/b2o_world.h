@@ -132,6 +132,10 @@ struct ContactPositionConstraint {
 
 struct Stats {
   long steps = 0, toiEvents = 0, toiCalls = 0, islands = 0, contactsCreated = 0, contactsDestroyed = 0;
+  long sweepHist[182] = {0};
+  long periodHist[34] = {0};   // diagnostic: period (1..32) of the sweep-state cycle when one is detected, [33] = none, [0] unused
+  long cycleAtSum = 0, cycleCount = 0;  // diagnostic: first velocity sweep after which the state is a fixed point (181 = never)
+  bool trackSweeps = false;
 };
 
 struct World;
@@ -1191,10 +1195,48 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
   contactSolver.InitializeVelocityConstraints();
   if (step.warmStarting) contactSolver.WarmStart();
   for (int jid : ijoints) JointInitVelocityConstraints(joints[jid], *this, step, positions.data(), velocities.data());
+  int fixedAt = -1;
+  std::vector<unsigned long long> hashes;
+  int cyclePeriod = 0, cycleAt = -1;
   for (int i = 0; i < step.velocityIterations; ++i) {
+    std::vector<Velocity> v0;
+    std::vector<ContactVelocityConstraint> c0;
+    std::vector<Joint> j0;
+    if (stats.trackSweeps && fixedAt < 0) {
+      v0 = velocities;
+      c0 = contactSolver.vcs;
+      for (int jid : ijoints) j0.push_back(joints[jid]);
+    }
     for (int jid : ijoints) JointSolveVelocityConstraints(joints[jid], step, velocities.data());
     contactSolver.SolveVelocityConstraints();
+    if (stats.trackSweeps && fixedAt < 0) {
+      bool same = true;
+      for (size_t k = 0; k < v0.size(); ++k)
+        same = same && v0[k].v.x == velocities[k].v.x && v0[k].v.y == velocities[k].v.y && v0[k].w == velocities[k].w;
+      for (size_t k = 0; k < c0.size(); ++k)
+        for (int q = 0; q < 2; ++q)
+          same = same && c0[k].points[q].normalImpulse == contactSolver.vcs[k].points[q].normalImpulse &&
+                 c0[k].points[q].tangentImpulse == contactSolver.vcs[k].points[q].tangentImpulse;
+      for (size_t k = 0; k < j0.size(); ++k) {
+        const Joint& jj = joints[ijoints[k]];
+        same = same && j0[k].impulse.x == jj.impulse.x && j0[k].impulse.y == jj.impulse.y && j0[k].impulse.z == jj.impulse.z &&
+               j0[k].motorImpulse == jj.motorImpulse;
+      }
+      if (same) fixedAt = i;
+    }
+    if (stats.trackSweeps && cyclePeriod == 0) {
+      unsigned long long hsh = 1469598103934665603ull;
+      auto mix = [&](float f) { if (f == 0.0f) f = 0.0f; unsigned u; std::memcpy(&u, &f, 4); hsh = (hsh ^ u) * 1099511628211ull; };
+      for (auto& vv : velocities) { mix(vv.v.x); mix(vv.v.y); mix(vv.w); }
+      for (auto& cc : contactSolver.vcs) for (int q = 0; q < 2; ++q) { mix(cc.points[q].normalImpulse); mix(cc.points[q].tangentImpulse); }
+      for (int jid : ijoints) { mix(joints[jid].impulse.x); mix(joints[jid].impulse.y); mix(joints[jid].impulse.z); mix(joints[jid].motorImpulse); }
+      for (int pp = 1; pp <= 32 && pp <= (int)hashes.size(); ++pp)
+        if (hashes[hashes.size() - pp] == hsh) { cyclePeriod = pp; cycleAt = i; break; }
+      hashes.push_back(hsh);
+    }
   }
+  if (stats.trackSweeps) { stats.periodHist[cyclePeriod == 0 ? 33 : cyclePeriod]++; if (cyclePeriod) { stats.cycleAtSum += cycleAt; stats.cycleCount++; } }
+  if (stats.trackSweeps) stats.sweepHist[fixedAt < 0 ? 181 : fixedAt + 1]++;
   contactSolver.StoreImpulses();
   for (int i = 0; i < bodyCount; ++i) {
     Vec2 c = positions[i].c;
