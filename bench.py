@@ -115,7 +115,9 @@ def main():
   if rank == 0:
     total_env_steps = float(args.steps) * T * N * world
     avg_launch_s = (sum(kernel_ms) / max(sum(launches), 1)) / 1e3
-    bytes_per_launch = ALG_BYTES.get(args.env, 0) * N
+    # one launch advances N envs by (T / launches-per-rollout) env-steps (fused rollout chunks)
+    steps_per_launch = T * args.steps / max(sum(launches), 1)
+    bytes_per_launch = ALG_BYTES.get(args.env, 0) * N * steps_per_launch
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     out = {
         'metric': 'env_steps_per_sec', 'value': total_env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world,
@@ -127,7 +129,7 @@ def main():
                    'awake_fraction_at_end': awake_frac},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'step_kernel',
-                     'avg_launch_ms': avg_launch_s * 1e3, 'alg_bytes_per_env_step': ALG_BYTES.get(args.env, 0),
+                     'avg_launch_ms': avg_launch_s * 1e3, 'env_steps_per_env_per_launch': steps_per_launch, 'alg_bytes_per_env_step': ALG_BYTES.get(args.env, 0),
                      'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'},
     }
     if not args.no_cpu_baseline and world == 1:

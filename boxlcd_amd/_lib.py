@@ -30,6 +30,7 @@ SYMBOLS = {
     'blcd_sync': (C.c_int, [C.c_void_p]),
     'blcd_stream': (C.c_void_p, [C.c_void_p]),
     'blcd_last_kernel_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    'blcd_debug_wave_times': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_debug_world_step': (C.c_int, [C.c_void_p, C.c_int32]),
     'blcd_debug_set_motor_speeds': (C.c_int, [C.c_void_p, C.c_void_p]),
     'blcd_debug_dump': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -188,6 +189,13 @@ class Handle:
     ms, n = C.c_float(0), C.c_int32(0)
     _check(self.lib.blcd_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
     return ms.value, n.value
+
+  def debug_wave_times(self):
+    out = np.zeros((self.n, 9), np.uint64)
+    n = self.lib.blcd_debug_wave_times(self._h, _ptr(out), self.n * 9)
+    if n < 0:
+      _check(n)
+    return out[:n]
 
   # parity hooks
   def debug_world_step(self, n=1):

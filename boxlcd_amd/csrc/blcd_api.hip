@@ -35,35 +35,112 @@ static int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBlock = 64;  // one wave per workgroup: N/64 workgroups spread over 256 CUs
 
+
+// observation (boxLCD/world_env.py:387-429, float64 glue) + LCD raster (:460-512) of one environment; `body(i, &p, &a, &sel)`
+// yields transform position, body angle and shape choice of body i.  Shared by obs_kernel and the fused rollout path.
+template <int H, typename RowT, typename ObsT, typename BodyFn>
+__device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn body, ObsT* __restrict__ obsRow,
+                                         uint8_t* __restrict__ lcdRow) {
+  bool ok = true;
+  if (obsRow) {
+    for (int i = 0; i < S->nobs; ++i) {
+      const DevObs od = S->obs[i];
+      Vec2 p;
+      float a;
+      int sel;
+      body(od.body, &p, &a, &sel);
+      double val;
+      if (od.kind == 0) val = (double)p.x;
+      else if (od.kind == 1) val = (double)p.y;
+      else {
+        if (od.kind >= 4) {  // transform.angle = atan2f(q.s, q.c)
+          Rot q;
+          q.Set(a);
+          a = atan2f(q.s, q.c);
+        }
+        val = (od.kind == 2 || od.kind == 4) ? cos((double)a) : sin((double)a);
+      }
+      double lo = (double)od.lo, hi = (double)od.hi;
+      obsRow[i] = (ObsT)(((val - lo) / (hi - lo) * 2.0) + -1.0);
+    }
+  }
+  if (lcdRow) {
+    Raster<H, RowT> r;
+    r.clear(S->lcdW, S->rasterVariant);
+    for (int i = 0; i < S->nb; ++i) {
+      Vec2 p;
+      float a;
+      int sel;
+      body(i, &p, &a, &sel);
+      Transform xf;
+      xf.p = p;
+      xf.q.Set(a);
+      ok = r.drawBody(&S->shapes[S->bodies[i].var[sel].shape], xf, (double)S->worldW, (double)S->lcdW) && ok;
+    }
+    r.write(lcdRow);
+  }
+  return ok;
+}
+
 template <int NB, int NJ, int NP>
 __global__ __launch_bounds__(kBlock) void step_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N,
-                                                      const float* __restrict__ actions, int nEnvSteps, int nWorldSteps,
-                                                      int setMotors) {
-  int e = blockIdx.x * kBlock + threadIdx.x;
-  if (e >= N) return;
+                                                      const int* __restrict__ eid, const float* __restrict__ actions,
+                                                      int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
+                                                      unsigned long long* __restrict__ waveTimes, long long actStride,
+                                                      uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut) {
+  unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
+  // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
+  // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
+  if ((int)threadIdx.x >= lanes) return;
+  int slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
+  if (slot >= N) return;
+  const int e = eid[slot];
   Env<NB, NJ, NP> env;
-  env.load(S, st, N, e);
-  if (nEnvSteps > 0) {
+  env.load(S, st, N, slot);
+  env.profOn = waveTimes != nullptr;
+  if (S->dbgSkip & 8) {
+  } else if (nEnvSteps > 0) {
+    // Fused rollout: this wave advances its environments through all nEnvSteps on its own (no grid-wide barrier between
+    // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.
+    const size_t lcdRow = (size_t)S->lcdH * S->lcdW;
     for (int t = 0; t < nEnvSteps; ++t) {
-      env.setMotorSpeeds(actions, N, e);
+      env.setMotorSpeeds(actions ? actions + (size_t)t * actStride : nullptr, N, e);
       for (int k = 0; k < S->substeps; ++k) env.worldStep();
+      if (lcdOut || obsOut) {
+        auto body = [&](int i, Vec2* p, float* a, int* sel) {
+          *p = env.xfp[i];
+          *a = env.a[i];
+          *sel = env.sel[i];
+        };
+        bool ok = emit_env<16, uint32_t, float>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr,
+                                                lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr);
+        if (!ok) env.fault |= FAULT_ELLIPSE;
+      }
     }
   } else {
     if (setMotors) env.setMotorSpeeds(actions, N, e);
     for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
   }
   env.checkFault();
-  env.store(st, N, e);
+  env.store(st, N, slot);
+  if (waveTimes) {
+    // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
+    unsigned long long* o = waveTimes + (size_t)blockIdx.x * 9;
+    if (threadIdx.x == 0) o[0] = __builtin_amdgcn_s_memrealtime() - t0;
+    for (int k = 0; k < 8; ++k) atomicMax(&o[1 + k], env.prof[k]);
+  }
 }
 
 // world construction for the listed envs: b2World::CreateBody + CreateFixture (proxy: tight AABB +- aabbExtension, buffered
 // as moved, e_newFixture), revolute joints with referenceAngle = bodyB.angle - bodyA.angle.
-__global__ void reset_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ idxs,
-                             int n, const float* __restrict__ poses, const int* __restrict__ shapeSel) {
+__global__ void reset_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ slotOf,
+                             const int* __restrict__ idxs, int n, const float* __restrict__ poses,
+                             const int* __restrict__ shapeSel) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   int e = idxs ? idxs[k] : k;
   if (e < 0 || e >= N) return;
+  e = slotOf[e];  // from here on `e` is the slot that stores this environment
   const int nb = S->nb, nj = S->nj, np = S->np;
   float ang[BLCD_MAX_BODIES];
   for (int i = 0; i < nb; ++i) {
@@ -117,12 +194,14 @@ __global__ void reset_kernel(const DevScene* __restrict__ S, float* __restrict__
 // b2Body::SetTransform per masked body: position first, then angle (two calls, like `body.position=`; `body.angle=`),
 // each followed by proxy synchronisation with zero displacement; new contacts are looked for at the next step.
 template <int NB, int NJ, int NP>
-__global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ idxs,
-                                 int n, const float* __restrict__ poses, const uint8_t* __restrict__ mask) {
+__global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ slotOf,
+                                 const int* __restrict__ idxs, int n, const float* __restrict__ poses,
+                                 const uint8_t* __restrict__ mask) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   int e = idxs ? idxs[k] : k;
   if (e < 0 || e >= N) return;
+  e = slotOf[e];
   Env<NB, NJ, NP> env;
   env.load(S, st, N, e);
   for (int i = 0; i < S->nb; ++i) {
@@ -148,48 +227,23 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 
 template <int H, typename RowT, typename ObsT>
 __global__ __launch_bounds__(kBlock) void obs_kernel(const DevScene* __restrict__ S, const float* st, int N,
-                                                     ObsT* __restrict__ obs, uint8_t* __restrict__ lcd,
-                                                     float* stw) {
-  int e = blockIdx.x * kBlock + threadIdx.x;
+                                                     const int* __restrict__ eid, ObsT* __restrict__ obs,
+                                                     uint8_t* __restrict__ lcd, float* stw) {
+  int e = blockIdx.x * kBlock + threadIdx.x;  // slot
   if (e >= N) return;
+  const int env = eid[e];
   const int nb = S->nb;
-  if (obs) {
-    for (int i = 0; i < S->nobs; ++i) {
-      const DevObs od = S->obs[i];
-      const float* p = st + (size_t)(od.body * kBodyFields) * N + e;
-      double val;
-      if (od.kind == 0) val = (double)p[(size_t)9 * N];
-      else if (od.kind == 1) val = (double)p[(size_t)10 * N];
-      else {
-        float a = p[(size_t)2 * N];
-        if (od.kind >= 4) {  // transform.angle = atan2f(q.s, q.c)
-          Rot q;
-          q.Set(a);
-          a = atan2f(q.s, q.c);
-        }
-        val = (od.kind == 2 || od.kind == 4) ? cos((double)a) : sin((double)a);
-      }
-      double lo = (double)od.lo, hi = (double)od.hi;
-      obs[(size_t)e * S->nobs + i] = (ObsT)(((val - lo) / (hi - lo) * 2.0) + -1.0);
-    }
-  }
-  if (lcd) {
-    Raster<H, RowT> r;
-    r.clear(S->lcdW, S->rasterVariant);
-    bool ok = true;
-    for (int i = 0; i < nb; ++i) {
-      const float* p = st + (size_t)(i * kBodyFields) * N + e;
-      Transform xf;
-      xf.p = V2(p[(size_t)9 * N], p[(size_t)10 * N]);
-      xf.q.Set(p[(size_t)2 * N]);
-      int sel = __float_as_int(p[(size_t)17 * N]);
-      ok = r.drawBody(&S->shapes[S->bodies[i].var[sel].shape], xf, (double)S->worldW, (double)S->lcdW) && ok;
-    }
-    r.write(lcd + (size_t)e * H * S->lcdW);
-    if (!ok && stw) {
-      size_t off = (size_t)(nb * kBodyFields + S->np * kPairFields + S->nj * kJointFields + 2) * N + e;
-      stw[off] = __uint_as_float(__float_as_uint(stw[off]) | ((uint32_t)FAULT_ELLIPSE << 8));
-    }
+  auto body = [&](int i, Vec2* p, float* a, int* sel) {
+    const float* q = st + (size_t)(i * kBodyFields) * N + e;
+    *p = V2(q[(size_t)9 * N], q[(size_t)10 * N]);
+    *a = q[(size_t)2 * N];
+    *sel = __float_as_int(q[(size_t)17 * N]);
+  };
+  bool ok = emit_env<H, RowT, ObsT>(S, body, obs ? obs + (size_t)env * S->nobs : nullptr,
+                                    lcd ? lcd + (size_t)env * H * S->lcdW : nullptr);
+  if (!ok && stw) {
+    size_t off = (size_t)(nb * kBodyFields + S->np * kPairFields + S->nj * kJointFields + 2) * N + e;
+    stw[off] = __uint_as_float(__float_as_uint(stw[off]) | ((uint32_t)FAULT_ELLIPSE << 8));
   }
 }
 
@@ -213,12 +267,14 @@ __global__ void render_poses_kernel(const DevScene* __restrict__ S, int m, const
   r.write(lcd + (size_t)k * H * S->lcdW);
 }
 
-__global__ void poses_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, float* __restrict__ out) {
+__global__ void poses_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, const int* __restrict__ eid,
+                             float* __restrict__ out) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
+  const int env = eid[e];
   for (int i = 0; i < S->nb; ++i) {
     const float* p = st + (size_t)(i * kBodyFields) * N + e;
-    float* o = out + ((size_t)e * S->nb + i) * 4;
+    float* o = out + ((size_t)env * S->nb + i) * 4;
     o[0] = p[(size_t)9 * N];
     o[1] = p[(size_t)10 * N];
     o[2] = p[(size_t)2 * N];
@@ -226,29 +282,31 @@ __global__ void poses_kernel(const DevScene* __restrict__ S, const float* __rest
   }
 }
 
-__global__ void faults_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int* __restrict__ out) {
+__global__ void faults_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, const int* __restrict__ eid,
+                              int* __restrict__ out) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   size_t off = (size_t)(S->nb * kBodyFields + S->np * kPairFields + S->nj * kJointFields + 2) * N + e;
-  out[e] = (int)(__float_as_uint(st[off]) >> 8);
+  out[eid[e]] = (int)(__float_as_uint(st[off]) >> 8);
 }
 
 // canonical dump (same layout as the parity oracle's dump)
-__global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, float* __restrict__ bodies,
-                            float* __restrict__ joints, float* __restrict__ pairs) {
+__global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, const int* __restrict__ eid,
+                            float* __restrict__ bodies, float* __restrict__ joints, float* __restrict__ pairs) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
+  const int env = eid[e];
   const int nb = S->nb, nj = S->nj, np = S->np;
   const int bmap[12] = {0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16};
   for (int i = 0; i < nb; ++i) {
     const float* p = st + (size_t)(i * kBodyFields) * N + e;
-    float* o = bodies + ((size_t)e * nb + i) * BLCD_BODY_STATE_FLOATS;
+    float* o = bodies + ((size_t)env * nb + i) * BLCD_BODY_STATE_FLOATS;
     for (int f = 0; f < 12; ++f) o[f] = p[(size_t)bmap[f] * N];
   }
   const float* pp = st + (size_t)(nb * kBodyFields) * N + e;
   for (int s = 0; s < np; ++s) {
     const float* p = pp + (size_t)(s * kPairFields) * N;
-    float* o = pairs + ((size_t)e * np + s) * BLCD_PAIR_STATE_FLOATS;
+    float* o = pairs + ((size_t)env * np + s) * BLCD_PAIR_STATE_FLOATS;
     for (int f = 0; f < BLCD_PAIR_STATE_FLOATS; ++f) o[f] = 0.0f;
     int fl = __float_as_int(p[0]);
     if (!(fl & PF_EXISTS)) continue;
@@ -271,12 +329,116 @@ __global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restr
   const float* jp = pp + (size_t)(np * kPairFields) * N;
   for (int j = 0; j < nj; ++j) {
     const float* p = jp + (size_t)(j * kJointFields) * N;
-    float* o = joints + ((size_t)e * nj + j) * BLCD_JOINT_STATE_FLOATS;
+    float* o = joints + ((size_t)env * nj + j) * BLCD_JOINT_STATE_FLOATS;
     o[0] = p[0];
     o[1] = p[(size_t)1 * N];
     o[2] = p[(size_t)2 * N];
     o[3] = p[(size_t)3 * N];
     o[4] = (float)__float_as_int(p[(size_t)4 * N]);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Re-binning: environments are independent, so WHERE an env's state lives is free.  Waves are 64 consecutive slots;
+// mixing asleep / free-flight / near-wall / touching envs in one wave leaves ~5 of 64 lanes active (measured, SQ PMC).
+// A stable counting sort of slots by work class makes waves homogeneous.  Stable => deterministic.
+//   class 0 asleep | 1 awake, no contact slot | 2 awake, contact slots, none touching | 3.. touching (by count)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kBins = 8;
+constexpr int kRebinBlock = 256;
+
+__device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot) {
+  const int nb = S->nb, nj = S->nj, np = S->np;
+  bool anyAwake = false;
+  for (int i = 0; i < nb; ++i) anyAwake = anyAwake || st[(size_t)(i * kBodyFields + 12) * N + slot] != 0.0f;
+  if (!anyAwake) return 0;
+  const float* pp = st + (size_t)(nb * kBodyFields) * N + slot;
+  int nc = __float_as_int(pp[(size_t)(np * kPairFields + nj * kJointFields + 3) * N]);
+  if (nc == 0) return 1;
+  int touching = 0;
+  for (int s2 = 0; s2 < np; ++s2)
+    if (__float_as_int(pp[(size_t)(s2 * kPairFields) * N]) & PF_TOUCHING) ++touching;
+  int c = 2 + touching;
+  return c < kBins ? c : kBins - 1;
+}
+
+__global__ __launch_bounds__(kRebinBlock) void rebin_hist_kernel(const DevScene* __restrict__ S, const float* __restrict__ st,
+                                                                 int N, uint8_t* __restrict__ keys, int* __restrict__ counts) {
+  __shared__ int h[kBins];
+  if (threadIdx.x < kBins) h[threadIdx.x] = 0;
+  __syncthreads();
+  int slot = blockIdx.x * kRebinBlock + threadIdx.x;
+  if (slot < N) {
+    int k = work_class(S, st, N, slot);
+    keys[slot] = (uint8_t)k;
+    atomicAdd(&h[k], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < kBins) counts[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];  // bin-major
+}
+
+// exclusive scan of counts[bin][block] in bin-major order (single block; nBlocks*kBins entries)
+__global__ void rebin_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int n) {
+  __shared__ int part[1024];
+  int tid = threadIdx.x, per = (n + 1023) / 1024;
+  int lo = tid * per, hi = lo + per < n ? lo + per : n;
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += counts[i];
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < 1024; ++i) {
+      int t = part[i];
+      part[i] = acc;
+      acc += t;
+    }
+  }
+  __syncthreads();
+  int acc = part[tid];
+  for (int i = lo; i < hi; ++i) {
+    offsets[i] = acc;
+    acc += counts[i];
+  }
+}
+
+// stable scatter: new slot = offset[bin][block] + rank of this slot among same-bin slots of the block (in slot order)
+__global__ __launch_bounds__(kRebinBlock) void rebin_move_kernel(const float* __restrict__ st, float* __restrict__ st2, int N,
+                                                                 int words, const uint8_t* __restrict__ keys,
+                                                                 const int* __restrict__ offsets, const int* __restrict__ eid,
+                                                                 int* __restrict__ eid2, int* __restrict__ slotOf) {
+  __shared__ int waveCount[kRebinBlock / 64][kBins];
+  int slot = blockIdx.x * kRebinBlock + threadIdx.x;
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int key = slot < N ? (int)keys[slot] : -1;
+  int rankInWave = 0;
+  for (int b = 0; b < kBins; ++b) {
+    unsigned long long m = __ballot(key == b);
+    if (key == b) rankInWave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) waveCount[wv][b] = __popcll(m);
+  }
+  __syncthreads();
+  if (slot >= N) return;
+  int base = offsets[key * gridDim.x + blockIdx.x];
+  for (int w2 = 0; w2 < wv; ++w2) base += waveCount[w2][key];
+  int dst = base + rankInWave;
+  for (int f = 0; f < words; ++f) st2[(size_t)f * N + dst] = st[(size_t)f * N + slot];
+  int e = eid[slot];
+  eid2[dst] = e;
+  slotOf[e] = dst;
+}
+
+__global__ void invert_kernel(const int* __restrict__ eid, int* __restrict__ slotOf, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slotOf[eid[i]] = i;
+}
+
+__global__ void iota_kernel(int* __restrict__ a, int* __restrict__ b, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    a[i] = i;
+    b[i] = i;
   }
 }
 
@@ -360,6 +522,7 @@ static int lower_scene(const blcd_scene_desc& d, DevScene* S) {
   S->velIters = d.vel_iters;
   S->posIters = d.pos_iters;
   S->nShapes = d.n_shapes;
+  S->dbgSkip = getenv("BLCD_DEBUG_SKIP") ? atoi(getenv("BLCD_DEBUG_SKIP")) : 0;
   // walls: boxLCD/world_env.py:311-314 — bottom, left, right, top
   float W = d.world_w, H = d.world_h;
   Vec2 ev[4][2] = {{V2(0, 0), V2(W, 0)}, {V2(0, 0), V2(0, H)}, {V2(W, 0), V2(W, H)}, {V2(0, H), V2(W, H)}};
@@ -465,6 +628,15 @@ struct blcd_handle_s {
   DevScene hostScene;
   DevScene* dScene = nullptr;
   float* st = nullptr;
+  float* st2 = nullptr;     // second state buffer for re-binning
+  int *eid = nullptr, *eid2 = nullptr, *slotOf = nullptr;
+  uint8_t* keys = nullptr;
+  int *binCounts = nullptr, *binOffsets = nullptr;
+  int rebinEvery = 0;       // 0 = never; k = after every k-th env step
+  int lanes = 64;           // environments per wave in step_kernel (BLCD_LANES)
+  int rolloutChunk = 50;    // env steps per fused rollout launch (BLCD_CHUNK; 0 = one launch per step + separate obs kernel)
+  unsigned long long* waveTimes = nullptr;  // per-wave duration of the last step launch (diagnostic, BLCD_WAVETIMES=1)
+  int stepsSinceRebin = 0;
   size_t words = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -553,8 +725,10 @@ static int pick_cfg(const DevScene& S) {
 }
 
 static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors,
-                       hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-  dim3 grid((h->N + kBlock - 1) / kBlock), block(kBlock);
+                       hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, long long actStride = 0, uint8_t* lcdOut = nullptr,
+                       float* obsOut = nullptr) {
+  const int lanes = h->lanes;
+  dim3 grid((h->N + lanes - 1) / lanes), block(kBlock);
   if (!e0) {
     e0 = h->ev0;
     e1 = h->ev1;
@@ -563,8 +737,8 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   int idx = 0;
 #define X(a, b, c)                                                                                              \
   if (h->cfg == idx)                                                                                            \
-    hipLaunchKernelGGL((step_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dActions, nEnvSteps, \
-                       nWorldSteps, setMotors);                                                                 \
+    hipLaunchKernelGGL((step_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, h->eid, dActions, nEnvSteps, \
+                       nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut);                                                                 \
   ++idx;
   BLCD_CONFIGS(X)
 #undef X
@@ -579,7 +753,7 @@ static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* 
   int idx = 0;
 #define X(a, b, c)                                                                                                  \
   if (h->cfg == idx)                                                                                                \
-    hipLaunchKernelGGL((set_poses_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dIdx, n, dPoses, dMask); \
+    hipLaunchKernelGGL((set_poses_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, h->slotOf, dIdx, n, dPoses, dMask); \
   ++idx;
   BLCD_CONFIGS(X)
 #undef X
@@ -587,13 +761,33 @@ static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* 
   return BLCD_OK;
 }
 
+// stable counting sort of slots by work class; swaps the state buffers
+static int launch_rebin(blcd_handle h) {
+  int nBlocks = (h->N + kRebinBlock - 1) / kRebinBlock;
+  hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, h->stream, h->dScene, h->st, h->N, h->keys, h->binCounts);
+  hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->binCounts, h->binOffsets, nBlocks * kBins);
+  hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, h->stream, h->st, h->st2, h->N, (int)h->words, h->keys,
+                     h->binOffsets, h->eid, h->eid2, h->slotOf);
+  HIPCHK(hipGetLastError());
+  std::swap(h->st, h->st2);
+  std::swap(h->eid, h->eid2);
+  h->stepsSinceRebin = 0;
+  return BLCD_OK;
+}
+static int maybe_rebin(blcd_handle h, int envSteps) {
+  if (h->rebinEvery <= 0) return BLCD_OK;
+  h->stepsSinceRebin += envSteps;
+  if (h->stepsSinceRebin >= h->rebinEvery) return launch_rebin(h);
+  return BLCD_OK;
+}
+
 template <typename ObsT>
 static int launch_obs(blcd_handle h, ObsT* dObs, uint8_t* dLcd) {
   dim3 grid((h->N + kBlock - 1) / kBlock), block(kBlock);
   if (h->hostScene.lcdH == 16)
-    hipLaunchKernelGGL((obs_kernel<16, uint32_t, ObsT>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dObs, dLcd, h->st);
+    hipLaunchKernelGGL((obs_kernel<16, uint32_t, ObsT>), grid, block, 0, h->stream, h->dScene, h->st, h->N, h->eid, dObs, dLcd, h->st);
   else
-    hipLaunchKernelGGL((obs_kernel<32, uint64_t, ObsT>), grid, block, 0, h->stream, h->dScene, h->st, h->N, dObs, dLcd, h->st);
+    hipLaunchKernelGGL((obs_kernel<32, uint64_t, ObsT>), grid, block, 0, h->stream, h->dScene, h->st, h->N, h->eid, dObs, dLcd, h->st);
   HIPCHK(hipGetLastError());
   return BLCD_OK;
 }
@@ -641,6 +835,28 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipMemcpy(h->dScene, &h->hostScene, sizeof(DevScene), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc((void**)&h->st, h->words * (size_t)n_envs * sizeof(float)));
   HIPCHK(hipMemset(h->st, 0, h->words * (size_t)n_envs * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->st2, h->words * (size_t)n_envs * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->eid, (size_t)n_envs * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&h->eid2, (size_t)n_envs * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&h->slotOf, (size_t)n_envs * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&h->keys, (size_t)n_envs));
+  {
+    int nBlocks = (n_envs + kRebinBlock - 1) / kRebinBlock;
+    HIPCHK(hipMalloc((void**)&h->binCounts, (size_t)nBlocks * kBins * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->binOffsets, (size_t)nBlocks * kBins * sizeof(int)));
+  }
+  hipLaunchKernelGGL(iota_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, n_envs);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  // re-binning pays when environments sleep / fly freely (no joints keep them awake); BLCD_REBIN overrides (0 = off)
+  h->rebinEvery = h->hostScene.nj == 0 ? 1 : 0;
+  if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
+  if (getenv("BLCD_WAVETIMES")) HIPCHK(hipMalloc((void**)&h->waveTimes, (size_t)n_envs * 9 * sizeof(unsigned long long)));
+  if (const char* ev = getenv("BLCD_CHUNK")) h->rolloutChunk = atoi(ev);
+  if (const char* ev = getenv("BLCD_LANES")) {
+    int l = atoi(ev);
+    if (l >= 1 && l <= 64) h->lanes = l;
+  }
   *out = h;
   return BLCD_OK;
 }
@@ -652,6 +868,13 @@ int blcd_destroy(blcd_handle h) {
   for (int k = 0; k < 4; ++k)
     if (h->stage[k]) (void)hipFree(h->stage[k]);
   if (h->st) (void)hipFree(h->st);
+  if (h->st2) (void)hipFree(h->st2);
+  if (h->eid) (void)hipFree(h->eid);
+  if (h->eid2) (void)hipFree(h->eid2);
+  if (h->slotOf) (void)hipFree(h->slotOf);
+  if (h->keys) (void)hipFree(h->keys);
+  if (h->binCounts) (void)hipFree(h->binCounts);
+  if (h->binOffsets) (void)hipFree(h->binOffsets);
   if (h->dScene) (void)hipFree(h->dScene);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -682,7 +905,7 @@ int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses
   if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
   if ((rc = in_ptr(h, 1, poses, (size_t)n * nb * 3 * sizeof(float), &dPoses))) return rc;
   if ((rc = in_ptr(h, 2, shape_sel, (size_t)n * nb * sizeof(int32_t), &dSel))) return rc;
-  hipLaunchKernelGGL(reset_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (const int*)dIdx, n,
+  hipLaunchKernelGGL(reset_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, h->slotOf, (const int*)dIdx, n,
                      (const float*)dPoses, (const int*)dSel);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -713,6 +936,7 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
   if ((rc = in_ptr(h, 0, actions, (size_t)h->N * h->hostScene.nact * sizeof(float), &dAct))) return rc;
   h->lastLaunches = 0;
   if ((rc = launch_step(h, (const float*)dAct, n_steps, 0, 0))) return rc;
+  if ((rc = maybe_rebin(h, n_steps))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipEventElapsedTime(&h->lastMs, h->ev0, h->ev1));
   return BLCD_OK;
@@ -736,17 +960,34 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     HIPCHK(hipEventCreate(&ev));
     h->evPool.push_back(ev);
   }
-  for (int t = 0; t < T; ++t) {
-    const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
-    if ((rc = launch_step(h, a, 1, 0, 0, h->evPool[2 * t], h->evPool[2 * t + 1]))) return rc;
-    if (dLcd || dObs) {
-      if ((rc = launch_obs<float>(h, dObs ? (float*)dObs + obsStep * t : nullptr, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr)))
+  int nLaunch = 0;
+  if (h->hostScene.lcdH == 16 && h->rolloutChunk > 0) {
+    // fused path: `chunk` env steps per launch, every wave runs its envs through the whole chunk and emits obs/LCD itself;
+    // slots are re-binned by work class between chunks
+    for (int t = 0; t < T; t += h->rolloutChunk) {
+      int c = T - t < h->rolloutChunk ? T - t : h->rolloutChunk;
+      const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
+      if ((rc = launch_step(h, a, c, 0, 0, h->evPool[2 * nLaunch], h->evPool[2 * nLaunch + 1], (long long)h->N * nact,
+                            dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr, dObs ? (float*)dObs + obsStep * t : nullptr)))
         return rc;
+      ++nLaunch;
+      if (t + c < T && (rc = maybe_rebin(h, c))) return rc;
+    }
+  } else {
+    for (int t = 0; t < T; ++t) {
+      const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
+      if ((rc = launch_step(h, a, 1, 0, 0, h->evPool[2 * t], h->evPool[2 * t + 1]))) return rc;
+      ++nLaunch;
+      if ((rc = maybe_rebin(h, 1))) return rc;
+      if (dLcd || dObs) {
+        if ((rc = launch_obs<float>(h, dObs ? (float*)dObs + obsStep * t : nullptr, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr)))
+          return rc;
+      }
     }
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   float total = 0.0f;  // step-kernel time only: each event pair brackets one step_kernel launch on this stream
-  for (int t = 0; t < T; ++t) {
+  for (int t = 0; t < nLaunch; ++t) {
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, h->evPool[2 * t], h->evPool[2 * t + 1]));
     total += ms;
@@ -806,7 +1047,7 @@ int blcd_get_poses(blcd_handle h, float* poses) {
   void* d;
   int rc;
   if ((rc = out_ptr(h, 1, poses, bytes, &d))) return rc;
-  hipLaunchKernelGGL(poses_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (float*)d);
+  hipLaunchKernelGGL(poses_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, h->eid, (float*)d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   return out_done(h, 1, poses, bytes, d);
@@ -819,7 +1060,8 @@ struct StateHeader {
 };
 int blcd_get_state(blcd_handle h, void* blob, size_t* size) {
   if (!h || !size) return fail(BLCD_ERR_INVALID, "blcd_get_state: bad arguments");
-  size_t need = sizeof(StateHeader) + h->words * (size_t)h->N * sizeof(float);
+  const size_t stBytes = h->words * (size_t)h->N * sizeof(float), idBytes = (size_t)h->N * sizeof(int);
+  size_t need = sizeof(StateHeader) + stBytes + idBytes;  // header | state in slot order | slot -> env id table
   if (!blob) {
     *size = need;
     return BLCD_OK;
@@ -829,13 +1071,15 @@ int blcd_get_state(blcd_handle h, void* blob, size_t* size) {
   StateHeader hd = {0x44434c42u, BLCD_VERSION, h->N, h->hostScene.nb, h->hostScene.nj, h->hostScene.np, (uint64_t)h->words};
   std::memcpy(blob, &hd, sizeof(hd));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy((char*)blob + sizeof(hd), h->st, need - sizeof(hd), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy((char*)blob + sizeof(hd), h->st, stBytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy((char*)blob + sizeof(hd) + stBytes, h->eid, idBytes, hipMemcpyDeviceToHost));
   *size = need;
   return BLCD_OK;
 }
 int blcd_set_state(blcd_handle h, const void* blob, size_t size) {
   if (!h || !blob) return fail(BLCD_ERR_INVALID, "blcd_set_state: bad arguments");
-  size_t need = sizeof(StateHeader) + h->words * (size_t)h->N * sizeof(float);
+  const size_t stBytes = h->words * (size_t)h->N * sizeof(float), idBytes = (size_t)h->N * sizeof(int);
+  size_t need = sizeof(StateHeader) + stBytes + idBytes;
   if (size != need) return fail(BLCD_ERR_INVALID, "blcd_set_state: size mismatch");
   StateHeader hd;
   std::memcpy(&hd, blob, sizeof(hd));
@@ -844,7 +1088,11 @@ int blcd_set_state(blcd_handle h, const void* blob, size_t size) {
     return fail(BLCD_ERR_INVALID, "blcd_set_state: snapshot belongs to a different scene/batch");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(h->st, (const char*)blob + sizeof(hd), need - sizeof(hd), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->st, (const char*)blob + sizeof(hd), stBytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->eid, (const char*)blob + sizeof(hd) + stBytes, idBytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(invert_kernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, h->N);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
   return BLCD_OK;
 }
 
@@ -854,7 +1102,7 @@ int blcd_get_faults(blcd_handle h, int32_t* flags) {
   const size_t bytes = (size_t)h->N * sizeof(int32_t);
   int rc = ensure_stage(h, 3, bytes);
   if (rc) return rc;
-  hipLaunchKernelGGL(faults_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (int*)h->stage[3]);
+  hipLaunchKernelGGL(faults_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, h->eid, (int*)h->stage[3]);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(flags, h->stage[3], bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -876,6 +1124,17 @@ int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches) {
   return BLCD_OK;
 }
 
+int blcd_debug_wave_times(blcd_handle h, uint64_t* out, int32_t cap) {
+  if (!h || !out) return fail(BLCD_ERR_INVALID, "blcd_debug_wave_times: bad arguments");
+  if (!h->waveTimes) return fail(BLCD_ERR_UNSUPPORTED, "set BLCD_WAVETIMES=1 before blcd_create");
+  int nw = (h->N + h->lanes - 1) / h->lanes;
+  if (nw * 9 > cap) nw = cap / 9;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(out, h->waveTimes, (size_t)nw * 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(h->waveTimes, 0, (size_t)nw * 9 * sizeof(uint64_t)));
+  return nw;
+}
 int blcd_debug_world_step(blcd_handle h, int32_t n) {
   if (!h || n < 0) return fail(BLCD_ERR_INVALID, "blcd_debug_world_step: bad arguments");
   HIPCHK(hipSetDevice(h->device));
@@ -905,7 +1164,7 @@ int blcd_debug_dump(blcd_handle h, float* bodies, float* joints, float* pairs) {
   if ((rc = ensure_stage(h, 1, bb))) return rc;
   if ((rc = ensure_stage(h, 2, jb))) return rc;
   if ((rc = ensure_stage(h, 3, pb))) return rc;
-  hipLaunchKernelGGL(dump_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, (float*)h->stage[1],
+  hipLaunchKernelGGL(dump_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, h->eid, (float*)h->stage[1],
                      (float*)h->stage[2], (float*)h->stage[3]);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(bodies, h->stage[1], bb, hipMemcpyDeviceToHost, h->stream));

@@ -16,6 +16,7 @@
 // per-thread storage for the duration of a launch.
 #pragma once
 #include "blcd_toi.h"
+#include "blcd_toi_wall.h"
 
 namespace blcd {
 
@@ -65,6 +66,7 @@ struct DevScene {
   float dt;
   int substeps, velIters, posIters;
   int nShapes;
+  int dbgSkip;  // timing-only ablation (BLCD_DEBUG_SKIP): 1 collide, 2 solve, 4 TOI, 8 everything  (results are wrong when set)
   Shape wallShape[4];
   AABB wallFat[4];
   Shape shapes[24];
@@ -124,17 +126,27 @@ struct Env {
   uint32_t wflags;
   int fault;
   float wallAlpha0[4];
+  // diagnostic per-wave cycle accounting (BLCD_WAVETIMES): 0 collide 1 solve 2 toi-search 3 toi-event 4 #toi calls 5 #events 6 sweeps 7 posIters
+  unsigned long long prof[8];
+  bool profOn;
   // --- island scratch ---
   Vec2 pc[NB], pv[NB];
   float pa[NB], pw[NB];
   VC vc[NP];
   uint8_t ic[NP];
+  // short-cycle detector for the velocity sweeps (islands without joints only)
+  static constexpr int kCycP = 4;                       // longest period looked for
+  static constexpr int kCycNB = NB < 3 ? NB : 3;        // eligible islands: at most this many dynamic bodies
+  static constexpr int kCycNC = NP < 6 ? NP : 6;        //                   and this many contacts
+  static constexpr int kCycW = 3 * kCycNB + 4 * kCycNC;
+  static constexpr int kCycSweeps = 24;                 // stop looking after this many sweeps
+  float cyc[kCycP][kCycW];
   uint8_t ij[NJ > 0 ? NJ : 1];
 
   // ------------------------------------------------------------------------------------------------
   // SoA state <-> thread
   // ------------------------------------------------------------------------------------------------
-  __device__ void load(const DevScene* scene, const float* __restrict__ st, int N, int e) {
+  __device__ __forceinline__ void load(const DevScene* scene, const float* __restrict__ st, int N, int e) {
     S = scene;
     const int nb = S->nb, nj = S->nj, np = S->np;
     awakeMask = 0;
@@ -206,9 +218,11 @@ struct Env {
         if (4 * k + t < NP) wl[4 * k + t] = (uint8_t)(word >> (8 * t));
     }
     for (int k = 0; k < 4; ++k) wallAlpha0[k] = 0.0f;
+    profOn = false;
+    for (int k = 0; k < 8; ++k) prof[k] = 0;
   }
 
-  __device__ void store(float* __restrict__ st, int N, int e) {
+  __device__ __forceinline__ void store(float* __restrict__ st, int N, int e) {
     const int nb = S->nb, nj = S->nj, np = S->np;
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
@@ -281,7 +295,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // proxy accessors (proxy p: 0..3 wall, 4+i dynamic body i)
   // ------------------------------------------------------------------------------------------------
-  __device__ Transform xfOf(int p) const {
+  __device__ __forceinline__ Transform xfOf(int p) const {
     Transform t;
     if (p < 4) {
       t.p = V2(0.0f, 0.0f);
@@ -293,14 +307,14 @@ struct Env {
     }
     return t;
   }
-  __device__ const Shape* shapeOf(int p) const {
+  __device__ __forceinline__ const Shape* shapeOf(int p) const {
     if (p < 4) return &S->wallShape[p];
     int i = p - 4;
     return &S->shapes[S->bodies[i].var[sel[i]].shape];
   }
-  __device__ AABB fatOf(int p) const { return p < 4 ? S->wallFat[p] : fat[p - 4]; }
-  __device__ bool awakeDyn(int i) const { return (awakeMask >> i) & 1; }
-  __device__ void wake(int p) {  // b2Body::SetAwake(true); wall flags are never consulted
+  __device__ __forceinline__ AABB fatOf(int p) const { return p < 4 ? S->wallFat[p] : fat[p - 4]; }
+  __device__ __forceinline__ bool awakeDyn(int i) const { return (awakeMask >> i) & 1; }
+  __device__ __forceinline__ void wake(int p) {  // b2Body::SetAwake(true); wall flags are never consulted
     if (p < 4) return;
     int i = p - 4;
     if (!((awakeMask >> i) & 1)) {
@@ -308,18 +322,18 @@ struct Env {
       sleepTime[i] = 0.0f;
     }
   }
-  __device__ void sleepBody(int i) {  // b2Body::SetAwake(false)
+  __device__ __forceinline__ void sleepBody(int i) {  // b2Body::SetAwake(false)
     awakeMask &= ~(1u << i);
     sleepTime[i] = 0.0f;
     v[i] = V2(0.0f, 0.0f);
     w[i] = 0.0f;
   }
-  __device__ void syncTransform(int i) {  // b2Body::SynchronizeTransform
+  __device__ __forceinline__ void syncTransform(int i) {  // b2Body::SynchronizeTransform
     q[i].Set(a[i]);
     xfp[i] = c[i] - Mul(q[i], lc[i]);
   }
   // fixture order of a slot after b2Contact::Create's type normalisation
-  __device__ void slotAB(int s, int* pA, int* pB) const {
+  __device__ __forceinline__ void slotAB(int s, int* pA, int* pB) const {
     int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
     if (pa_ >= 4) {
       int ta = shapeOf(pa_)->type, tb = shapeOf(pb_)->type;
@@ -337,7 +351,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // broad phase: b2Fixture::Synchronize + b2DynamicTree::MoveProxy, b2BroadPhase::UpdatePairs, AddPair
   // ------------------------------------------------------------------------------------------------
-  __device__ void synchronizeProxy(int i, const Transform& xf1, const Transform& xf2) {
+  __device__ __forceinline__ void synchronizeProxy(int i, const Transform& xf1, const Transform& xf2) {
     const Shape* sh = shapeOf(4 + i);
     AABB aabb1, aabb2, aabb;
     ShapeComputeAABB(sh, &aabb1, xf1);
@@ -356,13 +370,13 @@ struct Env {
     fat[i] = fb;
     moveMask |= 1u << i;
   }
-  __device__ void synchronizeFixtures(int i) {  // b2Body::SynchronizeFixtures
+  __device__ __forceinline__ void synchronizeFixtures(int i) {  // b2Body::SynchronizeFixtures
     Transform xf1;
     xf1.q.Set(a0[i]);
     xf1.p = c0[i] - Mul(xf1.q, lc[i]);
     synchronizeProxy(i, xf1, xfOf(4 + i));
   }
-  __device__ void findNewContacts(bool allMoved) {
+  __device__ __forceinline__ void findNewContacts(bool allMoved) {
     const int np = S->np;
     uint32_t mm = moveMask;
     moveMask = 0;
@@ -390,7 +404,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // b2Contact::Update (+ Evaluate dispatch), b2ContactManager::Collide
   // ------------------------------------------------------------------------------------------------
-  __device__ void updateContact(int s) {
+  __device__ __forceinline__ void updateContact(int s) {
     int pA, pB;
     slotAB(s, &pA, &pB);
     Manifold& m = man[s];
@@ -432,7 +446,7 @@ struct Env {
     if (touching) pflags[s] |= PF_TOUCHING; else pflags[s] &= ~PF_TOUCHING;
   }
 
-  __device__ void collide() {
+  __device__ __forceinline__ void collide() {
     int n = nc, out = 0;
     for (int k = 0; k < n; ++k) {
       int s = wl[k];
@@ -460,20 +474,20 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // island state accessors: dynamic bodies from pc/pa/pv/pw, walls constant
   // ------------------------------------------------------------------------------------------------
-  __device__ Vec2 Pc(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pc[p - 4]; }
-  __device__ float Pa(int p) const { return p < 4 ? 0.0f : pa[p - 4]; }
-  __device__ Vec2 Pv(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pv[p - 4]; }
-  __device__ float Pw(int p) const { return p < 4 ? 0.0f : pw[p - 4]; }
-  __device__ float mOf(int p) const { return p < 4 ? 0.0f : invMass[p - 4]; }
-  __device__ float iOf(int p) const { return p < 4 ? 0.0f : invI[p - 4]; }
-  __device__ Vec2 lcOf(int p) const { return p < 4 ? V2(0.0f, 0.0f) : lc[p - 4]; }
-  __device__ void setVel(int p, Vec2 vv, float ww) {
+  __device__ __forceinline__ Vec2 Pc(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pc[p - 4]; }
+  __device__ __forceinline__ float Pa(int p) const { return p < 4 ? 0.0f : pa[p - 4]; }
+  __device__ __forceinline__ Vec2 Pv(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pv[p - 4]; }
+  __device__ __forceinline__ float Pw(int p) const { return p < 4 ? 0.0f : pw[p - 4]; }
+  __device__ __forceinline__ float mOf(int p) const { return p < 4 ? 0.0f : invMass[p - 4]; }
+  __device__ __forceinline__ float iOf(int p) const { return p < 4 ? 0.0f : invI[p - 4]; }
+  __device__ __forceinline__ Vec2 lcOf(int p) const { return p < 4 ? V2(0.0f, 0.0f) : lc[p - 4]; }
+  __device__ __forceinline__ void setVel(int p, Vec2 vv, float ww) {
     if (p >= 4) {
       pv[p - 4] = vv;
       pw[p - 4] = ww;
     }
   }
-  __device__ void setPos(int p, Vec2 cc, float aa) {
+  __device__ __forceinline__ void setPos(int p, Vec2 cc, float aa) {
     if (p >= 4) {
       pc[p - 4] = cc;
       pa[p - 4] = aa;
@@ -483,7 +497,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // b2ContactSolver
   // ------------------------------------------------------------------------------------------------
-  __device__ void csInit(int count, bool warmStarting, float dtRatio) {
+  __device__ __forceinline__ void csInit(int count, bool warmStarting, float dtRatio) {
     for (int i = 0; i < count; ++i) {
       int s = ic[i];
       VC& c_ = vc[i];
@@ -513,7 +527,7 @@ struct Env {
     }
   }
 
-  __device__ void csInitVelocityConstraints(int count) {
+  __device__ __forceinline__ void csInitVelocityConstraints(int count) {
     for (int i = 0; i < count; ++i) {
       VC& c_ = vc[i];
       const Manifold* manifold = &man[c_.slot];
@@ -577,7 +591,7 @@ struct Env {
     }
   }
 
-  __device__ void csWarmStart(int count) {
+  __device__ __forceinline__ void csWarmStart(int count) {
     for (int i = 0; i < count; ++i) {
       VC& c_ = vc[i];
       int pA = c_.pA, pB = c_.pB;
@@ -604,7 +618,7 @@ struct Env {
   // Returns true iff some constraint applied a non-zero impulse in this sweep.  A sweep is a deterministic function of
   // (velocities, accumulated impulses); Box2D applies lambda = clamp(acc + d) - acc, so "no accumulator moved" means
   // every applied impulse was exactly zero and the state is a fixed point: all remaining sweeps are no-ops.
-  __device__ bool csSolveVelocityConstraints(int count) {
+  __device__ __forceinline__ bool csSolveVelocityConstraints(int count) {
     bool changed = false;
     for (int i = 0; i < count; ++i) {
       VC& c_ = vc[i];
@@ -703,7 +717,7 @@ struct Env {
     return changed;
   }
 
-  __device__ void csStoreImpulses(int count) {
+  __device__ __forceinline__ void csStoreImpulses(int count) {
     for (int i = 0; i < count; ++i) {
       VC& c_ = vc[i];
       Manifold& m = man[c_.slot];
@@ -715,7 +729,7 @@ struct Env {
   }
 
   // b2PositionSolverManifold::Initialize + one b2ContactSolver position iteration (baumgarte/limit differ for TOI)
-  __device__ float csSolvePosition(int count, bool toiMode, int toiBody) {
+  __device__ __forceinline__ float csSolvePosition(int count, bool toiMode, int toiBody) {
     float minSeparation = 0.0f;
     for (int i = 0; i < count; ++i) {
       VC& c_ = vc[i];
@@ -791,7 +805,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // b2RevoluteJoint
   // ------------------------------------------------------------------------------------------------
-  __device__ void jointInit(int j, bool warmStarting, float dtRatio) {
+  __device__ __forceinline__ void jointInit(int j, bool warmStarting, float dtRatio) {
     const DevJoint& J = S->joints[j];
     int A = J.bodyA, B = J.bodyB;
     float aA = pa[A];
@@ -856,7 +870,7 @@ struct Env {
     pw[B] = wB;
   }
 
-  __device__ bool jointSolveVelocity(int j, float dt) {
+  __device__ __forceinline__ bool jointSolveVelocity(int j, float dt) {
     bool changed = false;
     const DevJoint& J = S->joints[j];
     int A = J.bodyA, B = J.bodyB;
@@ -944,7 +958,7 @@ struct Env {
     return changed;
   }
 
-  __device__ bool jointSolvePosition(int j) {
+  __device__ __forceinline__ bool jointSolvePosition(int j) {
     const DevJoint& J = S->joints[j];
     int A = J.bodyA, B = J.bodyB;
     Vec2 cA = pc[A];
@@ -1002,10 +1016,83 @@ struct Env {
     return positionError <= kLinearSlop && angularError <= kAngularSlop;
   }
 
+
+  // ------------------------------------------------------------------------------------------------
+  // The velocity sweeps.  Box2D always runs `velIters` sweeps; here the loop ends early when that provably cannot change
+  // the result (the parity oracle runs all of them):
+  //  * fixed point: a sweep applied exactly zero impulse everywhere => every later sweep is a no-op;
+  //  * short cycle: the sweep is a deterministic function of (velocities, accumulated impulses); if the state after sweep k
+  //    equals the state after sweep k-p the sequence is p-periodic from there on, so the state after the last sweep is the
+  //    stored state at index k-p+((velIters-1-k) mod p).  (1-ulp rounding ping-pong, period 2-4, is what keeps ~1 % of
+  //    solves from ever reaching a fixed point.)
+  // ------------------------------------------------------------------------------------------------
+  __device__ __forceinline__ void cycPack(uint32_t ibmask, int nic, float* dst) const {
+    int o = 0;
+    for (int i = 0; i < NB; ++i) {
+      if (!((ibmask >> i) & 1)) continue;
+      dst[o++] = pv[i].x;
+      dst[o++] = pv[i].y;
+      dst[o++] = pw[i];
+    }
+    for (int k = 0; k < nic; ++k)
+      for (int j = 0; j < 2; ++j) {
+        bool live = j < vc[k].pointCount;
+        dst[o++] = live ? vc[k].points[j].normalImpulse : 0.0f;
+        dst[o++] = live ? vc[k].points[j].tangentImpulse : 0.0f;
+      }
+    for (; o < kCycW; ++o) dst[o] = 0.0f;
+  }
+  __device__ __forceinline__ void cycUnpack(uint32_t ibmask, int nic, const float* src) {
+    int o = 0;
+    for (int i = 0; i < NB; ++i) {
+      if (!((ibmask >> i) & 1)) continue;
+      pv[i].x = src[o++];
+      pv[i].y = src[o++];
+      pw[i] = src[o++];
+    }
+    for (int k = 0; k < nic; ++k)
+      for (int j = 0; j < 2; ++j) {
+        if (j < vc[k].pointCount) {
+          vc[k].points[j].normalImpulse = src[o];
+          vc[k].points[j].tangentImpulse = src[o + 1];
+        }
+        o += 2;
+      }
+  }
+  __device__ __forceinline__ void velocitySweeps(uint32_t ibmask, int nic, int nij, float h) {
+    const int velIters = S->velIters;
+    bool watch = nij == 0 && nic > 0 && nic <= kCycNC && __popc(ibmask) <= kCycNB;
+    for (int it = 0; it < velIters; ++it) {
+      bool changed = false;
+      for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
+      changed = csSolveVelocityConstraints(nic) || changed;
+      prof[6] += 1;
+      if (!changed) break;
+      if (watch && it < kCycSweeps) {
+        float cur[kCycW];
+        cycPack(ibmask, nic, cur);
+        bool found = false;
+        for (int p = 1; p <= kCycP && p <= it; ++p) {
+          const float* old = cyc[(it - p) & (kCycP - 1)];
+          bool same = true;
+          for (int q = 0; q < kCycW; ++q) same = same && (old[q] == cur[q]);
+          if (same) {
+            int r = (velIters - 1 - it) % p;
+            if (r != 0) cycUnpack(ibmask, nic, cyc[(it - p + r) & (kCycP - 1)]);
+            found = true;
+            break;
+          }
+        }
+        if (found) break;
+        for (int q = 0; q < kCycW; ++q) cyc[it & (kCycP - 1)][q] = cur[q];
+      }
+    }
+  }
+
   // ------------------------------------------------------------------------------------------------
   // b2Island::Solve for the island {bodies in ibmask, contacts ic[0..nic), joints ij[0..nij)}
   // ------------------------------------------------------------------------------------------------
-  __device__ void integratePositions(uint32_t ibmask, float h) {
+  __device__ __forceinline__ void integratePositions(uint32_t ibmask, float h) {
     const int nb = S->nb;
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
@@ -1033,7 +1120,7 @@ struct Env {
     }
   }
 
-  __device__ void islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
+  __device__ __forceinline__ void islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
     const int nb = S->nb;
     Vec2 gravity = S->gravity;
     for (int i = 0; i < NB; ++i) {
@@ -1056,19 +1143,14 @@ struct Env {
     csInitVelocityConstraints(nic);
     csWarmStart(nic);
     for (int k = 0; k < nij; ++k) jointInit(ij[k], true, dtRatio);
-    const int velIters = S->velIters;
-    for (int it = 0; it < velIters; ++it) {
-      bool changed = false;
-      for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
-      changed = csSolveVelocityConstraints(nic) || changed;
-      if (!changed) break;  // bitwise fixed point: the remaining sweeps cannot change anything
-    }
+    velocitySweeps(ibmask, nic, nij, h);
     csStoreImpulses(nic);
     integratePositions(ibmask, h);
     bool positionSolved = false;
     const int posIters = S->posIters;
     for (int it = 0; it < posIters; ++it) {
       float minSeparation = csSolvePosition(nic, false, -1);
+      prof[7] += 1;
       bool contactsOkay = minSeparation >= -3.0f * kLinearSlop;
       bool jointsOkay = true;
       for (int k = 0; k < nij; ++k) {
@@ -1112,7 +1194,7 @@ struct Env {
   }
 
   // b2World::Solve
-  __device__ void solve(float h, float dtRatio) {
+  __device__ __forceinline__ void solve(float h, float dtRatio) {
     const int nb = S->nb;
     uint32_t bodyIsland = 0, jointIsland = 0;
     for (int k = 0; k < nc; ++k) pflags[wl[k]] &= ~PF_ISLAND;
@@ -1176,7 +1258,7 @@ struct Env {
   // b2World::SolveTOI (+ b2Island::SolveTOI).  Without bullets only dynamic-vs-wall contacts are eligible, so a TOI
   // island is one dynamic body plus the walls it touches at the time of impact.
   // ------------------------------------------------------------------------------------------------
-  __device__ Sweep sweepOf(int p) const {
+  __device__ __forceinline__ Sweep sweepOf(int p) const {
     Sweep sw;
     if (p < 4) {
       sw.localCenter = V2(0.0f, 0.0f);
@@ -1194,7 +1276,7 @@ struct Env {
     }
     return sw;
   }
-  __device__ void advanceBody(int i, float alpha) {  // b2Body::Advance
+  __device__ __forceinline__ void advanceBody(int i, float alpha) {  // b2Body::Advance
     Sweep sw = sweepOf(4 + i);
     sw.Advance(alpha);
     c0[i] = sw.c0;
@@ -1206,7 +1288,7 @@ struct Env {
     xfp[i] = c[i] - Mul(q[i], lc[i]);
   }
 
-  __device__ void solveTOI(float dt) {
+  __device__ __forceinline__ void solveTOI(float dt) {
     const int nb = S->nb;
     for (int i = 0; i < NB; ++i)
       if (i < nb) alpha0[i] = 0.0f;
@@ -1246,11 +1328,16 @@ struct Env {
             a0[b] = sw.a0;
             alpha0[b] = sw.alpha0;
           }
-          DistanceProxy proxyA, proxyB;
-          proxyA.Set(shapeOf(pa_));
-          proxyB.Set(shapeOf(pb_));
           TOIOutput output;
-          TimeOfImpact(&output, &proxyA, sweepOf(pa_), &proxyB, sweepOf(pb_), 1.0f);
+          {
+            TOIWall<kShapeVerts> tw;  // wall edge vs moving shape, everything in registers (blcd_toi_wall.h)
+            tw.A.a0 = S->wallShape[pa_].v[0];
+            tw.A.a1 = S->wallShape[pa_].v[1];
+            tw.A.radius = S->wallShape[pa_].radius;
+            tw.B.load(shapeOf(pb_));
+            tw.run(&output, sweepOf(pb_));
+          }
+          prof[4] += 1;
           float beta = output.t;
           if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
           else alpha = 1.0f;
@@ -1289,6 +1376,8 @@ struct Env {
         continue;
       }
       wake(pB);
+      prof[5] += 1;
+      unsigned long long e0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
       // build the TOI island: contact list of the dynamic body, static others only
       uint32_t wallIsland = 1u << wA;
       int nic = 0;
@@ -1327,9 +1416,7 @@ struct Env {
       c0[b] = pc[b];
       a0[b] = pa[b];
       csInitVelocityConstraints(nic);
-      const int velIters = S->velIters;
-      for (int it = 0; it < velIters; ++it)
-        if (!csSolveVelocityConstraints(nic)) break;
+      velocitySweeps(1u << b, nic, 0, h);
       integratePositions(1u << b, h);
       c[b] = pc[b];
       a[b] = pa[b];
@@ -1343,11 +1430,12 @@ struct Env {
         if (S->pairs[s].a == pB || S->pairs[s].b == pB) pflags[s] &= ~(PF_TOI | PF_ISLAND);
       }
       findNewContacts(false);
+      if (profOn) prof[3] += __builtin_amdgcn_s_memtime() - e0_;
     }
   }
 
   // b2World::Step
-  __device__ void worldStep() {
+  __device__ __forceinline__ void worldStep() {
     if (wflags & WF_NEWFIXTURE) {
       findNewContacts(true);
       wflags &= ~WF_NEWFIXTURE;
@@ -1355,14 +1443,24 @@ struct Env {
     float dt = S->dt;
     float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
     float dtRatio = inv_dt0 * dt;
-    collide();
-    solve(dt, dtRatio);
-    solveTOI(dt);
+    const int skip = S->dbgSkip;
+    unsigned long long c0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
+    if (!(skip & 1)) collide();
+    unsigned long long c1_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
+    if (!(skip & 2)) solve(dt, dtRatio);
+    unsigned long long c2_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
+    if (!(skip & 4)) solveTOI(dt);
+    if (profOn) {
+      unsigned long long c3_ = __builtin_amdgcn_s_memtime();
+      prof[0] += c1_ - c0_;
+      prof[1] += c2_ - c1_;
+      prof[2] += c3_ - c2_;
+    }
     inv_dt0 = inv_dt;
   }
 
   // action -> joint.motorSpeed (boxLCD/utils.py:117 mapto, world_env.py:441); b2RevoluteJoint::SetMotorSpeed wakes both bodies
-  __device__ void setMotorSpeeds(const float* __restrict__ actions, int N, int e) {
+  __device__ __forceinline__ void setMotorSpeeds(const float* __restrict__ actions, int N, int e) {
     const int nj = S->nj, nact = S->nact;
     for (int j = 0; j < NJ; ++j) {
       if (j >= nj) break;
@@ -1377,7 +1475,7 @@ struct Env {
     }
   }
 
-  __device__ void checkFault() {
+  __device__ __forceinline__ void checkFault() {
     const int nb = S->nb;
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
