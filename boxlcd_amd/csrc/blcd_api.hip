@@ -108,9 +108,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevScene* __restrict
       for (int k = 0; k < S->substeps; ++k) env.worldStep();
       if (lcdOut || obsOut) {
         auto body = [&](int i, Vec2* p, float* a, int* sel) {
-          *p = env.xfp[i];
-          *a = env.a[i];
-          *sel = env.sel[i];
+          const int bi = NB == 1 ? 0 : i;  // static index for single-body scenes (keeps env in registers)
+          *p = env.xfp[bi];
+          *a = env.a[bi];
+          *sel = env.sel[bi];
         };
         bool ok = emit_env<16, uint32_t, float>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr,
                                                 lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr);

@@ -3,6 +3,7 @@
 // (Box2D 2.3.x semantics).  Shapes come from boxLCD/world_env.py:273,311-314 and
 // boxLCD/world_defs.py:82-83,103-108.
 #pragma once
+#include <utility>
 #include "blcd_math.h"
 
 namespace blcd {
@@ -212,10 +213,13 @@ BLCD_HD static inline void ShapeComputeAABB(const Shape* s, AABB* aabb, const Tr
   }
   Vec2 lower = Mul(xf, s->v[0]);
   Vec2 upper = lower;
-  for (int i = 1; i < s->count; ++i) {
-    Vec2 v = Mul(xf, s->v[i]);
-    lower = Min(lower, v);
-    upper = Max(upper, v);
+#pragma unroll
+  for (int i = 1; i < kShapeVerts; ++i) {
+    if (i < s->count) {
+      Vec2 v = Mul(xf, s->v[i]);
+      lower = Min(lower, v);
+      upper = Max(upper, v);
+    }
   }
   Vec2 r = V2(s->radius, s->radius);
   aabb->lo = lower - r;
@@ -274,7 +278,9 @@ struct WorldManifold {
       case kManifoldFaceA: {
         normal = Mul(xfA.q, manifold->localNormal);
         Vec2 planePoint = Mul(xfA, manifold->localPoint);
-        for (int i = 0; i < manifold->pointCount; ++i) {
+#pragma unroll
+        for (int i = 0; i < kMaxManifoldPoints; ++i) {
+          if (i >= manifold->pointCount) break;
           Vec2 clipPoint = Mul(xfB, manifold->points[i].localPoint);
           Vec2 cA = clipPoint + (radiusA - Dot(clipPoint - planePoint, normal)) * normal;
           Vec2 cB = clipPoint - radiusB * normal;
@@ -285,7 +291,9 @@ struct WorldManifold {
       case kManifoldFaceB: {
         normal = Mul(xfB.q, manifold->localNormal);
         Vec2 planePoint = Mul(xfB, manifold->localPoint);
-        for (int i = 0; i < manifold->pointCount; ++i) {
+#pragma unroll
+        for (int i = 0; i < kMaxManifoldPoints; ++i) {
+          if (i >= manifold->pointCount) break;
           Vec2 clipPoint = Mul(xfA, manifold->points[i].localPoint);
           Vec2 cB = clipPoint + (radiusB - Dot(clipPoint - planePoint, normal)) * normal;
           Vec2 cA = clipPoint - radiusA * normal;
@@ -298,22 +306,39 @@ struct WorldManifold {
   }
 };
 
+// manifold->points[idx] = {localPoint, id} without a run-time indexed store (impulses are left as they are, like Box2D)
+BLCD_HD static inline void PutManifoldPoint(Manifold* m, int idx, const ManifoldPoint& cp) {
+  if (idx == 0) {
+    m->points[0].localPoint = cp.localPoint;
+    m->points[0].id = cp.id;
+  } else {
+    m->points[1].localPoint = cp.localPoint;
+    m->points[1].id = cp.id;
+  }
+}
+
 // b2ClipSegmentToLine (b2Collision.cpp)
 BLCD_HD static inline int ClipSegmentToLine(ClipVertex vOut[2], const ClipVertex vIn[2], Vec2 normal, float offset, int vertexIndexA) {
-  int numOut = 0;
+  // Same selection as Box2D's `vOut[numOut++] = ...` sequence, written without run-time indexed stores (register
+  // residency): when the segment crosses the line exactly one end point is inside, so the interpolated vertex lands in
+  // vOut[1]; when both are inside vOut = vIn.
   float distance0 = Dot(normal, vIn[0].v) - offset;
   float distance1 = Dot(normal, vIn[1].v) - offset;
-  if (distance0 <= 0.0f) vOut[numOut++] = vIn[0];
-  if (distance1 <= 0.0f) vOut[numOut++] = vIn[1];
+  const bool in0 = distance0 <= 0.0f, in1 = distance1 <= 0.0f;
+  int numOut = (in0 ? 1 : 0) + (in1 ? 1 : 0);
+  ClipVertex o0 = in0 ? vIn[0] : vIn[1];
+  ClipVertex o1 = vIn[1];
   if (distance0 * distance1 < 0.0f) {
     float interp = distance0 / (distance0 - distance1);
-    vOut[numOut].v = vIn[0].v + interp * (vIn[1].v - vIn[0].v);
-    vOut[numOut].id.cf.indexA = (uint8_t)vertexIndexA;
-    vOut[numOut].id.cf.indexB = vIn[0].id.cf.indexB;
-    vOut[numOut].id.cf.typeA = kFeatureVertex;
-    vOut[numOut].id.cf.typeB = kFeatureFace;
+    o1.v = vIn[0].v + interp * (vIn[1].v - vIn[0].v);
+    o1.id.cf.indexA = (uint8_t)vertexIndexA;
+    o1.id.cf.indexB = vIn[0].id.cf.indexB;
+    o1.id.cf.typeA = kFeatureVertex;
+    o1.id.cf.typeB = kFeatureFace;
     ++numOut;
   }
+  vOut[0] = o0;
+  vOut[1] = o1;
   return numOut;
 }
 
@@ -525,19 +550,23 @@ BLCD_HD static inline void CollidePolygons(Manifold* manifold, const Shape* poly
   manifold->localNormal = localNormal;
   manifold->localPoint = planePoint;
   int pointCount = 0;
+#pragma unroll
   for (int i = 0; i < kMaxManifoldPoints; ++i) {
     float separation = Dot(normal, clipPoints2[i].v) - frontOffset;
     if (separation <= totalRadius) {
-      ManifoldPoint* cp = manifold->points + pointCount;
-      cp->localPoint = MulT(xf2, clipPoints2[i].v);
-      cp->id = clipPoints2[i].id;
+      ManifoldPoint cp;
+      cp.normalImpulse = 0.0f;
+      cp.tangentImpulse = 0.0f;
+      cp.localPoint = MulT(xf2, clipPoints2[i].v);
+      cp.id = clipPoints2[i].id;
       if (flip) {
-        ContactFeature cf = cp->id.cf;
-        cp->id.cf.indexA = cf.indexB;
-        cp->id.cf.indexB = cf.indexA;
-        cp->id.cf.typeA = cf.typeB;
-        cp->id.cf.typeB = cf.typeA;
+        ContactFeature cf = cp.id.cf;
+        cp.id.cf.indexA = cf.indexB;
+        cp.id.cf.indexB = cf.indexA;
+        cp.id.cf.typeA = cf.typeB;
+        cp.id.cf.typeB = cf.typeA;
       }
+      PutManifoldPoint(manifold, pointCount, cp);
       ++pointCount;
     }
   }
@@ -608,6 +637,17 @@ BLCD_HD static inline void CollideEdgeAndCircle(Manifold* manifold, const Shape*
   manifold->points[0].localPoint = circleB->v[0];
 }
 
+// pv[idx] for a run-time idx as a compare/select chain (keeps the array in registers)
+template <size_t... I>
+BLCD_HD static inline Vec2 SelVecImpl(const Vec2 (&a)[kShapeVerts], int idx, std::index_sequence<I...>) {
+  float x = a[0].x, y = a[0].y;
+  ((x = (idx == (int)(I + 1)) ? a[I + 1].x : x, y = (idx == (int)(I + 1)) ? a[I + 1].y : y), ...);
+  return Vec2{x, y};
+}
+BLCD_HD static inline Vec2 SelVec(const Vec2 (&a)[kShapeVerts], int idx) {
+  return SelVecImpl(a, idx, std::make_index_sequence<kShapeVerts - 1>{});
+}
+
 // b2EPCollider::Collide (b2CollideEdge.cpp) — isolated edge
 BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape* edgeA, const Transform& xfA, const Shape* polygonB,
                                          const Transform& xfB) {
@@ -639,9 +679,15 @@ BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape
   // polygonB in frame A
   Vec2 pv[kShapeVerts], pn[kShapeVerts];
   int pcount = polygonB->count;
-  for (int i = 0; i < pcount; ++i) {
-    pv[i] = Mul(m_xf, polygonB->v[i]);
-    pn[i] = Mul(m_xf.q, polygonB->n[i]);
+#pragma unroll
+  for (int i = 0; i < kShapeVerts; ++i) {
+    if (i < pcount) {
+      pv[i] = Mul(m_xf, polygonB->v[i]);
+      pn[i] = Mul(m_xf.q, polygonB->n[i]);
+    } else {
+      pv[i] = V2(0.0f, 0.0f);
+      pn[i] = V2(0.0f, 0.0f);
+    }
   }
   float m_radius = 2.0f * kPolygonRadius;
   manifold->pointCount = 0;
@@ -651,9 +697,12 @@ BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape
   edgeAxis.type = kEdgeA;
   edgeAxis.index = m_front ? 0 : 1;
   edgeAxis.separation = FLT_MAX;
-  for (int i = 0; i < pcount; ++i) {
-    float s = Dot(m_normal, pv[i] - m_v1);
-    if (s < edgeAxis.separation) edgeAxis.separation = s;
+#pragma unroll
+  for (int i = 0; i < kShapeVerts; ++i) {
+    if (i < pcount) {
+      float s = Dot(m_normal, pv[i] - m_v1);
+      if (s < edgeAxis.separation) edgeAxis.separation = s;
+    }
   }
   if (edgeAxis.type == kUnknown) return;
   if (edgeAxis.separation > m_radius) return;
@@ -665,7 +714,10 @@ BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape
   polygonAxis.separation = -FLT_MAX;
   {
     Vec2 perp = V2(-m_normal.y, m_normal.x);
-    for (int i = 0; i < pcount; ++i) {
+    bool stop = false;
+#pragma unroll
+    for (int i = 0; i < kShapeVerts; ++i) {
+      if (i >= pcount || stop) continue;
       Vec2 n = -pn[i];
       float s1 = Dot(n, pv[i] - m_v1);
       float s2 = Dot(n, pv[i] - m_v2);
@@ -674,7 +726,8 @@ BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape
         polygonAxis.type = kEdgeB;
         polygonAxis.index = i;
         polygonAxis.separation = s;
-        break;
+        stop = true;
+        continue;
       }
       if (Dot(n, perp) >= 0.0f) {
         if (Dot(n - m_upperLimit, m_normal) < -kAngularSlop) continue;
@@ -711,21 +764,24 @@ BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape
     manifold->type = kManifoldFaceA;
     int bestIndex = 0;
     float bestValue = Dot(m_normal, pn[0]);
-    for (int i = 1; i < pcount; ++i) {
-      float value = Dot(m_normal, pn[i]);
-      if (value < bestValue) {
-        bestValue = value;
-        bestIndex = i;
+#pragma unroll
+    for (int i = 1; i < kShapeVerts; ++i) {
+      if (i < pcount) {
+        float value = Dot(m_normal, pn[i]);
+        if (value < bestValue) {
+          bestValue = value;
+          bestIndex = i;
+        }
       }
     }
     int i1 = bestIndex;
     int i2 = i1 + 1 < pcount ? i1 + 1 : 0;
-    ie[0].v = pv[i1];
+    ie[0].v = SelVec(pv, i1);
     ie[0].id.cf.indexA = 0;
     ie[0].id.cf.indexB = (uint8_t)i1;
     ie[0].id.cf.typeA = kFeatureFace;
     ie[0].id.cf.typeB = kFeatureVertex;
-    ie[1].v = pv[i2];
+    ie[1].v = SelVec(pv, i2);
     ie[1].id.cf.indexA = 0;
     ie[1].id.cf.indexB = (uint8_t)i2;
     ie[1].id.cf.typeA = kFeatureFace;
@@ -757,9 +813,9 @@ BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape
     ie[1].id.cf.typeB = kFeatureFace;
     rf.i1 = primaryAxis.index;
     rf.i2 = rf.i1 + 1 < pcount ? rf.i1 + 1 : 0;
-    rf.v1 = pv[rf.i1];
-    rf.v2 = pv[rf.i2];
-    rf.normal = pn[rf.i1];
+    rf.v1 = SelVec(pv, rf.i1);
+    rf.v2 = SelVec(pv, rf.i2);
+    rf.normal = SelVec(pn, rf.i1);
   }
   rf.sideNormal1 = V2(rf.normal.y, -rf.normal.x);
   rf.sideNormal2 = -rf.sideNormal1;
@@ -780,20 +836,24 @@ BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape
     manifold->localPoint = polygonB->v[rf.i1];
   }
   int pointCount = 0;
+#pragma unroll
   for (int i = 0; i < kMaxManifoldPoints; ++i) {
     float separation = Dot(rf.normal, clipPoints2[i].v - rf.v1);
     if (separation <= m_radius) {
-      ManifoldPoint* cp = manifold->points + pointCount;
+      ManifoldPoint cp;
+      cp.normalImpulse = 0.0f;
+      cp.tangentImpulse = 0.0f;
       if (primaryAxis.type == kEdgeA) {
-        cp->localPoint = MulT(m_xf, clipPoints2[i].v);
-        cp->id = clipPoints2[i].id;
+        cp.localPoint = MulT(m_xf, clipPoints2[i].v);
+        cp.id = clipPoints2[i].id;
       } else {
-        cp->localPoint = clipPoints2[i].v;
-        cp->id.cf.typeA = clipPoints2[i].id.cf.typeB;
-        cp->id.cf.typeB = clipPoints2[i].id.cf.typeA;
-        cp->id.cf.indexA = clipPoints2[i].id.cf.indexB;
-        cp->id.cf.indexB = clipPoints2[i].id.cf.indexA;
+        cp.localPoint = clipPoints2[i].v;
+        cp.id.cf.typeA = clipPoints2[i].id.cf.typeB;
+        cp.id.cf.typeB = clipPoints2[i].id.cf.typeA;
+        cp.id.cf.indexA = clipPoints2[i].id.cf.indexB;
+        cp.id.cf.indexB = clipPoints2[i].id.cf.indexA;
       }
+      PutManifoldPoint(manifold, pointCount, cp);
       ++pointCount;
     }
   }

@@ -214,13 +214,39 @@ struct TOIWall {
     return dist;
   }
 
+  // ---- exact memo of sweepB.GetTransform(t): the TOI iteration asks for the same t repeatedly (t1 in the outer loop, the
+  // separation function's Initialize/Evaluate; tMax in every FindMinSeparation; the root it just found).  The sweep is
+  // fixed during one TOI query, so GetTransform is a pure function of t and replaying a stored result is bit-identical.
+  float mkA, mkB, mkC;      // keys (NaN = empty)
+  Transform mxA, mxB, mxC;  // A: current t1, B: tMax, C: most recent other t
+  __device__ __forceinline__ void memoReset() {
+    mkA = mkB = mkC = __builtin_nanf("");
+  }
+  __device__ __forceinline__ Transform xfAt(float t) {
+    if (t == mkA) return mxA;
+    if (t == mkB) return mxB;
+    if (t == mkC) return mxC;
+    Transform xf;
+    sweepB.GetTransform(&xf, t);
+    mkC = t;
+    mxC = xf;
+    return xf;
+  }
+  __device__ __forceinline__ void memoPinT1(float t, const Transform& xf) {
+    mkA = t;
+    mxA = xf;
+  }
+  __device__ __forceinline__ void memoPinMax(float t, const Transform& xf) {
+    mkB = t;
+    mxB = xf;
+  }
+
   // ---- b2SeparationFunction ----
   int sfType;  // 0 points, 1 faceA, 2 faceB
   Vec2 sfLocalPoint, sfAxis;
 
   __device__ __forceinline__ void sfInitialize(const CacheR& cache, float t1) {
-    Transform xfB;
-    sweepB.GetTransform(&xfB, t1);
+    Transform xfB = xfAt(t1);
     if (cache.count == 1) {
       sfType = 0;
       Vec2 pointA = A.vertex(cache.iA0);
@@ -253,9 +279,8 @@ struct TOIWall {
       if (s < 0.0f) sfAxis = -sfAxis;
     }
   }
-  __device__ __forceinline__ float sfFindMinSeparation(int* indexA, int* indexB, float t) const {
-    Transform xfB;
-    sweepB.GetTransform(&xfB, t);
+  __device__ __forceinline__ float sfFindMinSeparation(int* indexA, int* indexB, float t) {
+    Transform xfB = xfAt(t);
     if (sfType == 0) {
       *indexA = A.support(sfAxis);
       *indexB = B.support(MulT(xfB.q, -sfAxis));
@@ -278,9 +303,8 @@ struct TOIWall {
       return Dot(pointA - pointB, normal);
     }
   }
-  __device__ __forceinline__ float sfEvaluate(int indexA, int indexB, float t) const {
-    Transform xfB;
-    sweepB.GetTransform(&xfB, t);
+  __device__ __forceinline__ float sfEvaluate(int indexA, int indexB, float t) {
+    Transform xfB = xfAt(t);
     if (sfType == 0) {
       Vec2 pointA = A.vertex(indexA);
       Vec2 pointB = Mul(xfB, B.vertex(indexB));
@@ -316,9 +340,10 @@ struct TOIWall {
     cache.metric = 0.0f;
     cache.iA0 = cache.iA1 = cache.iA2 = cache.iB0 = cache.iB1 = cache.iB2 = 0;
     v1.indexA = v1.indexB = v2.indexA = v2.indexB = v3.indexA = v3.indexB = 0;
+    memoReset();
     for (;;) {
-      Transform xfB;
-      sweepB.GetTransform(&xfB, t1);
+      Transform xfB = xfAt(t1);
+      memoPinT1(t1, xfB);
       float dist = distance(cache, xfB);
       if (dist <= 0.0f) {
         output->state = kTOIOverlapped;
@@ -333,6 +358,10 @@ struct TOIWall {
       sfInitialize(cache, t1);
       bool done = false;
       float t2 = tMax;
+      if (!(mkB == tMax)) {
+        Transform xm = xfAt(tMax);
+        memoPinMax(tMax, xm);
+      }
       int pushBackIter = 0;
       for (;;) {
         int indexA, indexB;

@@ -15,6 +15,7 @@
 // State lives SoA in HBM ([field][env], env fastest => coalesced 256 B lines per wave) and is staged into
 // per-thread storage for the duration of a launch.
 #pragma once
+#include <utility>
 #include "blcd_toi.h"
 #include "blcd_toi_wall.h"
 
@@ -93,8 +94,86 @@ struct VC {
   int pointCount;
 };
 
+// Register residency for small scenes: a per-thread array that is indexed with a run-time value lives in scratch (private
+// memory, ~500+ cycles per dependent access at one or two waves per SIMD).  For arrays of at most 4 elements the helpers
+// below turn a run-time index into a compare/select chain over statically indexed elements, so the array can be
+// scalarised into VGPRs; larger arrays fall back to plain indexing.
+// (A loop / struct-assignment formulation gets re-rolled into an indexed scratch access by LLVM; selecting 32-bit words with
+// compile-time unrolled fold expressions does not.)
+template <typename T, int N, size_t... K>
+__device__ __forceinline__ void selWordsGet(const T (&a)[N], int i, int t, uint32_t* r, std::index_sequence<K...>) {
+  uint32_t w[sizeof...(K)];
+  __builtin_memcpy(w, &a[t], sizeof(T));
+  ((r[K] = (i == t) ? w[K] : r[K]), ...);
+}
+template <typename T, int N, size_t... Ts>
+__device__ __forceinline__ T selGetImpl(const T (&a)[N], int i, std::index_sequence<Ts...>) {
+  constexpr size_t W = sizeof(T) / 4;
+  static_assert(sizeof(T) % 4 == 0, "selGet needs whole 32-bit words");
+  uint32_t r[W];
+  __builtin_memcpy(r, &a[0], sizeof(T));
+  (selWordsGet(a, i, (int)(Ts + 1), r, std::make_index_sequence<W>{}), ...);
+  T out;
+  __builtin_memcpy(&out, r, sizeof(T));
+  return out;
+}
+template <int N, typename T>
+__device__ __forceinline__ T selGet(const T (&a)[N], int i) {
+  if constexpr (N <= 4) return selGetImpl(a, i, std::make_index_sequence<N - 1>{});
+  else return a[i];
+}
+template <typename T, int N, size_t... K>
+__device__ __forceinline__ void selWordsSet(T (&a)[N], int i, int t, const uint32_t* v, std::index_sequence<K...>) {
+  uint32_t w[sizeof...(K)];
+  __builtin_memcpy(w, &a[t], sizeof(T));
+  ((w[K] = (i == t) ? v[K] : w[K]), ...);
+  __builtin_memcpy(&a[t], w, sizeof(T));
+}
+template <typename T, int N, size_t... Ts>
+__device__ __forceinline__ void selSetImpl(T (&a)[N], int i, const T& val, std::index_sequence<Ts...>) {
+  constexpr size_t W = sizeof(T) / 4;
+  uint32_t v[W];
+  __builtin_memcpy(v, &val, sizeof(T));
+  (selWordsSet(a, i, (int)Ts, v, std::make_index_sequence<W>{}), ...);
+}
+template <int N, typename T>
+__device__ __forceinline__ void selSet(T (&a)[N], int i, const T& v) {
+  if constexpr (N <= 4) selSetImpl(a, i, v, std::make_index_sequence<N>{});
+  else a[i] = v;
+}
+// up to 4 small integers packed in one register (N <= 4), plain byte array otherwise
+template <int N>
+struct ByteVec {
+  uint32_t w;
+  uint8_t arr[N > 4 ? N : 1];
+  __device__ __forceinline__ int get(int i) const {
+    if constexpr (N <= 4) return (int)((w >> (8 * i)) & 0xffu);
+    else return arr[i];
+  }
+  __device__ __forceinline__ void set(int i, int v) {
+    if constexpr (N <= 4) w = (w & ~(0xffu << (8 * i))) | ((uint32_t)(v & 0xff) << (8 * i));
+    else arr[i] = (uint8_t)v;
+  }
+  __device__ __forceinline__ void orBits(int i, int bits) { set(i, get(i) | bits); }
+  __device__ __forceinline__ void clearBits(int i, int bits) { set(i, get(i) & ~bits); }
+  __device__ __forceinline__ void insertFront(int count, int v) {  // shift [0,count) up by one, put v at 0
+    if constexpr (N <= 4) {
+      w = (w << 8) | (uint32_t)(v & 0xff);
+    } else {
+      for (int k = count; k > 0; --k) arr[k] = arr[k - 1];
+      arr[0] = (uint8_t)v;
+    }
+  }
+};
+
 template <int NB, int NJ, int NP>
 struct Env {
+  // Island contact capacity.  A single body in the walled arena can touch at most two (adjacent) walls at once, so the
+  // one-body configuration keeps two constraint slots in registers; an island that would need more raises FAULT_OVERFLOW
+  // (reported through blcd_get_faults) instead of silently dropping physics.
+  static constexpr int kMaxC = NB == 1 ? (NP < 2 ? NP : 2) : NP;
+  static constexpr int kU = kMaxC <= 4 ? kMaxC : 1;   // unroll factor of the constraint loops (full unroll => static vc[] indices)
+  static constexpr int kUS = NP <= 4 ? NP : 1;        // unroll factor of the per-slot load/store loops
   const DevScene* S;
   // --- dynamic bodies ---
   Vec2 c[NB], v[NB], c0[NB], xfp[NB];
@@ -106,10 +185,10 @@ struct Env {
   float invMass[NB], invI[NB];
   Vec2 lc[NB];
   // --- pair slots ---
-  uint8_t wl[NP];
+  ByteVec<NP> wl;        // world contact list, newest first (slot ids)
   int nc;
-  uint8_t pflags[NP];
-  uint8_t toiCount[NP];
+  ByteVec<NP> pflags;
+  ByteVec<NP> toiCount;
   float toi[NP];
   Manifold man[NP];
   // --- joints ---
@@ -132,15 +211,15 @@ struct Env {
   // --- island scratch ---
   Vec2 pc[NB], pv[NB];
   float pa[NB], pw[NB];
-  VC vc[NP];
-  uint8_t ic[NP];
+  VC vc[kMaxC];
+  ByteVec<NP> ic;
   // short-cycle detector for the velocity sweeps (islands without joints only)
   static constexpr int kCycP = 4;                       // longest period looked for
   static constexpr int kCycNB = NB < 3 ? NB : 3;        // eligible islands: at most this many dynamic bodies
-  static constexpr int kCycNC = NP < 6 ? NP : 6;        //                   and this many contacts
+  static constexpr int kCycNC = kMaxC < 6 ? kMaxC : 6;  //                   and this many contacts
   static constexpr int kCycW = 3 * kCycNB + 4 * kCycNC;
   static constexpr int kCycSweeps = 24;                 // stop looking after this many sweeps
-  float cyc[kCycP][kCycW];
+
   uint8_t ij[NJ > 0 ? NJ : 1];
 
   // ------------------------------------------------------------------------------------------------
@@ -173,11 +252,12 @@ struct Env {
       lc[i] = var.localCenter;
     }
     const float* pp = st + (size_t)(nb * kBodyFields) * N + e;
+#pragma unroll kUS
     for (int s = 0; s < NP; ++s) {
       if (s >= np) break;
       const float* p = pp + (size_t)(s * kPairFields) * N;
       int fl = __float_as_int(p[0]);
-      pflags[s] = (uint8_t)fl;
+      pflags.set(s, fl);
       int tc = __float_as_int(p[(size_t)1 * N]);
       Manifold& m = man[s];
       m.type = tc & 0xff;
@@ -191,8 +271,8 @@ struct Env {
         m.points[k].tangentImpulse = r[(size_t)3 * N];
         m.points[k].id.key = __float_as_uint(r[(size_t)4 * N]);
       }
-      toiCount[s] = 0;
-      toi[s] = 1.0f;
+      toiCount.set(s, 0);
+      selSet(toi, s, (float)(1.0f));
     }
     const float* jp = pp + (size_t)(np * kPairFields) * N;
     for (int j = 0; j < NJ; ++j) {
@@ -215,7 +295,7 @@ struct Env {
       if (4 * k >= np) break;
       uint32_t word = __float_as_uint(wp[(size_t)(4 + k) * N]);
       for (int t = 0; t < 4; ++t)
-        if (4 * k + t < NP) wl[4 * k + t] = (uint8_t)(word >> (8 * t));
+        if (4 * k + t < NP) wl.set(4 * k + t, (int)((word >> (8 * t)) & 0xffu));
     }
     for (int k = 0; k < 4; ++k) wallAlpha0[k] = 0.0f;
     profOn = false;
@@ -247,10 +327,11 @@ struct Env {
       // sel is immutable during stepping
     }
     float* pp = st + (size_t)(nb * kBodyFields) * N + e;
+#pragma unroll kUS
     for (int s = 0; s < NP; ++s) {
       if (s >= np) break;
       float* p = pp + (size_t)(s * kPairFields) * N;
-      p[0] = __int_as_float((int)(pflags[s] & (PF_EXISTS | PF_TOUCHING | PF_ENABLED)));
+      p[0] = __int_as_float((int)(pflags.get(s) & (PF_EXISTS | PF_TOUCHING | PF_ENABLED)));
       const Manifold& m = man[s];
       p[(size_t)1 * N] = __int_as_float((m.type & 0xff) | (m.pointCount << 8));
       p[(size_t)2 * N] = m.localNormal.x;
@@ -287,7 +368,7 @@ struct Env {
       if (4 * k >= np) break;
       uint32_t word = 0;
       for (int t = 0; t < 4; ++t)
-        if (4 * k + t < NP) word |= (uint32_t)wl[4 * k + t] << (8 * t);
+        if (4 * k + t < NP) word |= (uint32_t)wl.get(4 * k + t) << (8 * t);
       wp[(size_t)(4 + k) * N] = __uint_as_float(word);
     }
   }
@@ -295,6 +376,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // proxy accessors (proxy p: 0..3 wall, 4+i dynamic body i)
   // ------------------------------------------------------------------------------------------------
+  static __device__ __forceinline__ int bi(int p) { return NB == 1 ? 0 : p - 4; }  // body index of a dynamic proxy
   __device__ __forceinline__ Transform xfOf(int p) const {
     Transform t;
     if (p < 4) {
@@ -302,21 +384,32 @@ struct Env {
       t.q.s = 0.0f;
       t.q.c = 1.0f;
     } else {
-      t.p = xfp[p - 4];
-      t.q = q[p - 4];
+      t.p = xfp[bi(p)];
+      t.q = q[bi(p)];
     }
     return t;
   }
   __device__ __forceinline__ const Shape* shapeOf(int p) const {
     if (p < 4) return &S->wallShape[p];
-    int i = p - 4;
+    int i = bi(p);
     return &S->shapes[S->bodies[i].var[sel[i]].shape];
   }
-  __device__ __forceinline__ AABB fatOf(int p) const { return p < 4 ? S->wallFat[p] : fat[p - 4]; }
+  __device__ __forceinline__ AABB fatOf(int p) const {
+    // value selects on purpose: `cond ? global : member` would become a select of POINTERS, which makes the member's
+    // address escape as a flat pointer and keeps the whole Env object in scratch
+    const AABB w = S->wallFat[p < 4 ? p : 0];
+    const AABB d = fat[p < 4 ? 0 : bi(p)];
+    AABB r;
+    r.lo.x = p < 4 ? w.lo.x : d.lo.x;
+    r.lo.y = p < 4 ? w.lo.y : d.lo.y;
+    r.hi.x = p < 4 ? w.hi.x : d.hi.x;
+    r.hi.y = p < 4 ? w.hi.y : d.hi.y;
+    return r;
+  }
   __device__ __forceinline__ bool awakeDyn(int i) const { return (awakeMask >> i) & 1; }
   __device__ __forceinline__ void wake(int p) {  // b2Body::SetAwake(true); wall flags are never consulted
     if (p < 4) return;
-    int i = p - 4;
+    int i = bi(p);
     if (!((awakeMask >> i) & 1)) {
       awakeMask |= 1u << i;
       sleepTime[i] = 0.0f;
@@ -381,21 +474,21 @@ struct Env {
     uint32_t mm = moveMask;
     moveMask = 0;
     if (!allMoved && mm == 0) return;
+#pragma unroll kUS
     for (int s = 0; s < NP; ++s) {
       if (s >= np) break;
-      if (pflags[s] & PF_EXISTS) continue;
+      if (pflags.get(s) & PF_EXISTS) continue;
       int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
       bool moved = allMoved || (pa_ >= 4 && ((mm >> (pa_ - 4)) & 1)) || ((mm >> (pb_ - 4)) & 1);
       if (!moved) continue;
       if (!TestOverlap(fatOf(pa_), fatOf(pb_))) continue;
       // b2ContactManager::AddPair: new contact at the front of the world list; wake both bodies
-      for (int k = nc; k > 0; --k) wl[k] = wl[k - 1];
-      wl[0] = (uint8_t)s;
+      wl.insertFront(nc, s);
       ++nc;
-      pflags[s] = PF_EXISTS | PF_ENABLED;
+      pflags.set(s, PF_EXISTS | PF_ENABLED);
       man[s].pointCount = 0;
-      toiCount[s] = 0;
-      toi[s] = 1.0f;
+      toiCount.set(s, 0);
+      selSet(toi, s, (float)(1.0f));
       wake(pa_);
       wake(pb_);
     }
@@ -407,10 +500,10 @@ struct Env {
   __device__ __forceinline__ void updateContact(int s) {
     int pA, pB;
     slotAB(s, &pA, &pB);
-    Manifold& m = man[s];
+    Manifold m = selGet(man, s);
     Manifold oldManifold = m;
-    pflags[s] |= PF_ENABLED;
-    bool wasTouching = (pflags[s] & PF_TOUCHING) != 0;
+    pflags.orBits(s, PF_ENABLED);
+    bool wasTouching = (pflags.get(s) & PF_TOUCHING) != 0;
     const Shape* shA = shapeOf(pA);
     const Shape* shB = shapeOf(pB);
     Transform xfA = xfOf(pA), xfB = xfOf(pB);
@@ -425,12 +518,16 @@ struct Env {
       CollideCircles(&m, shA, xfA, shB, xfB);
     }
     bool touching = m.pointCount > 0;
-    for (int i = 0; i < m.pointCount; ++i) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= m.pointCount) break;
       ManifoldPoint* mp2 = m.points + i;
       mp2->normalImpulse = 0.0f;
       mp2->tangentImpulse = 0.0f;
       uint32_t key = mp2->id.key;
-      for (int j = 0; j < oldManifold.pointCount; ++j) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j >= oldManifold.pointCount) break;
         const ManifoldPoint* mp1 = oldManifold.points + j;
         if (mp1->id.key == key) {
           mp2->normalImpulse = mp1->normalImpulse;
@@ -443,30 +540,33 @@ struct Env {
       wake(pA);
       wake(pB);
     }
-    if (touching) pflags[s] |= PF_TOUCHING; else pflags[s] &= ~PF_TOUCHING;
+    if (touching) pflags.orBits(s, PF_TOUCHING); else pflags.clearBits(s, PF_TOUCHING);
+    selSet(man, s, m);
   }
 
   __device__ __forceinline__ void collide() {
     int n = nc, out = 0;
     for (int k = 0; k < n; ++k) {
-      int s = wl[k];
+      int s = wl.get(k);
       int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
       bool activeA = pa_ >= 4 && awakeDyn(pa_ - 4);
       bool activeB = awakeDyn(pb_ - 4);
       if (activeA || activeB) {
         if (!TestOverlap(fatOf(pa_), fatOf(pb_))) {
           // b2ContactManager::Destroy + b2Contact::Destroy
-          if (man[s].pointCount > 0) {
+          Manifold dm = selGet(man, s);
+          if (dm.pointCount > 0) {
             wake(pa_);
             wake(pb_);
           }
-          pflags[s] = 0;
-          man[s].pointCount = 0;
+          pflags.set(s, 0);
+          dm.pointCount = 0;
+          selSet(man, s, dm);
           continue;
         }
         updateContact(s);
       }
-      wl[out++] = (uint8_t)s;
+      wl.set(out++, s);
     }
     nc = out;
   }
@@ -474,23 +574,23 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // island state accessors: dynamic bodies from pc/pa/pv/pw, walls constant
   // ------------------------------------------------------------------------------------------------
-  __device__ __forceinline__ Vec2 Pc(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pc[p - 4]; }
-  __device__ __forceinline__ float Pa(int p) const { return p < 4 ? 0.0f : pa[p - 4]; }
-  __device__ __forceinline__ Vec2 Pv(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pv[p - 4]; }
-  __device__ __forceinline__ float Pw(int p) const { return p < 4 ? 0.0f : pw[p - 4]; }
-  __device__ __forceinline__ float mOf(int p) const { return p < 4 ? 0.0f : invMass[p - 4]; }
-  __device__ __forceinline__ float iOf(int p) const { return p < 4 ? 0.0f : invI[p - 4]; }
-  __device__ __forceinline__ Vec2 lcOf(int p) const { return p < 4 ? V2(0.0f, 0.0f) : lc[p - 4]; }
+  __device__ __forceinline__ Vec2 Pc(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pc[bi(p)]; }
+  __device__ __forceinline__ float Pa(int p) const { return p < 4 ? 0.0f : pa[bi(p)]; }
+  __device__ __forceinline__ Vec2 Pv(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pv[bi(p)]; }
+  __device__ __forceinline__ float Pw(int p) const { return p < 4 ? 0.0f : pw[bi(p)]; }
+  __device__ __forceinline__ float mOf(int p) const { return p < 4 ? 0.0f : invMass[bi(p)]; }
+  __device__ __forceinline__ float iOf(int p) const { return p < 4 ? 0.0f : invI[bi(p)]; }
+  __device__ __forceinline__ Vec2 lcOf(int p) const { return p < 4 ? V2(0.0f, 0.0f) : lc[bi(p)]; }
   __device__ __forceinline__ void setVel(int p, Vec2 vv, float ww) {
     if (p >= 4) {
-      pv[p - 4] = vv;
-      pw[p - 4] = ww;
+      pv[bi(p)] = vv;
+      pw[bi(p)] = ww;
     }
   }
   __device__ __forceinline__ void setPos(int p, Vec2 cc, float aa) {
     if (p >= 4) {
-      pc[p - 4] = cc;
-      pa[p - 4] = aa;
+      pc[bi(p)] = cc;
+      pa[bi(p)] = aa;
     }
   }
 
@@ -498,10 +598,12 @@ struct Env {
   // b2ContactSolver
   // ------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void csInit(int count, bool warmStarting, float dtRatio) {
-    for (int i = 0; i < count; ++i) {
-      int s = ic[i];
+#pragma unroll kU
+    for (int i = 0; i < kMaxC; ++i) {
+      if (i >= count) break;
+      int s = ic.get(i);
       VC& c_ = vc[i];
-      const Manifold& m = man[s];
+      const Manifold m = selGet(man, s);
       c_.slot = s;
       slotAB(s, &c_.pA, &c_.pB);
       c_.friction = S->pairs[s].friction;
@@ -509,7 +611,9 @@ struct Env {
       c_.pointCount = m.pointCount;
       c_.K.ex = c_.K.ey = V2(0.0f, 0.0f);
       c_.normalMass.ex = c_.normalMass.ey = V2(0.0f, 0.0f);
-      for (int j = 0; j < m.pointCount; ++j) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j >= m.pointCount) break;
         VCPoint& p = c_.points[j];
         if (warmStarting) {
           p.normalImpulse = dtRatio * m.points[j].normalImpulse;
@@ -528,9 +632,12 @@ struct Env {
   }
 
   __device__ __forceinline__ void csInitVelocityConstraints(int count) {
-    for (int i = 0; i < count; ++i) {
+#pragma unroll kU
+    for (int i = 0; i < kMaxC; ++i) {
+      if (i >= count) break;
       VC& c_ = vc[i];
-      const Manifold* manifold = &man[c_.slot];
+      const Manifold mcopy = selGet(man, c_.slot);
+      const Manifold* manifold = &mcopy;
       int pA = c_.pA, pB = c_.pB;
       float radiusA = shapeOf(pA)->radius, radiusB = shapeOf(pB)->radius;
       float mA = mOf(pA), mB = mOf(pB), iA = iOf(pA), iB = iOf(pB);
@@ -552,7 +659,9 @@ struct Env {
       worldManifold.Initialize(manifold, xfA, radiusA, xfB, radiusB);
       c_.normal = worldManifold.normal;
       int pointCount = c_.pointCount;
-      for (int j = 0; j < pointCount; ++j) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j >= pointCount) break;
         VCPoint* vcp = c_.points + j;
         vcp->rA = worldManifold.points[j] - cA;
         vcp->rB = worldManifold.points[j] - cB;
@@ -592,7 +701,9 @@ struct Env {
   }
 
   __device__ __forceinline__ void csWarmStart(int count) {
-    for (int i = 0; i < count; ++i) {
+#pragma unroll kU
+    for (int i = 0; i < kMaxC; ++i) {
+      if (i >= count) break;
       VC& c_ = vc[i];
       int pA = c_.pA, pB = c_.pB;
       float mA = mOf(pA), iA = iOf(pA), mB = mOf(pB), iB = iOf(pB);
@@ -602,7 +713,9 @@ struct Env {
       float wB = Pw(pB);
       Vec2 normal = c_.normal;
       Vec2 tangent = Cross(normal, 1.0f);
-      for (int j = 0; j < c_.pointCount; ++j) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j >= c_.pointCount) break;
         VCPoint* vcp = c_.points + j;
         Vec2 P = vcp->normalImpulse * normal + vcp->tangentImpulse * tangent;
         wA -= iA * Cross(vcp->rA, P);
@@ -620,7 +733,9 @@ struct Env {
   // every applied impulse was exactly zero and the state is a fixed point: all remaining sweeps are no-ops.
   __device__ __forceinline__ bool csSolveVelocityConstraints(int count) {
     bool changed = false;
-    for (int i = 0; i < count; ++i) {
+#pragma unroll kU
+    for (int i = 0; i < kMaxC; ++i) {
+      if (i >= count) break;
       VC& c_ = vc[i];
       int pA = c_.pA, pB = c_.pB;
       float mA = mOf(pA), iA = iOf(pA), mB = mOf(pB), iB = iOf(pB);
@@ -632,7 +747,9 @@ struct Env {
       Vec2 normal = c_.normal;
       Vec2 tangent = Cross(normal, 1.0f);
       float friction = c_.friction;
-      for (int j = 0; j < pointCount; ++j) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j >= pointCount) break;
         VCPoint* vcp = c_.points + j;
         Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
         float vt = Dot(dv, tangent) - 0.0f;
@@ -718,22 +835,30 @@ struct Env {
   }
 
   __device__ __forceinline__ void csStoreImpulses(int count) {
-    for (int i = 0; i < count; ++i) {
+#pragma unroll kU
+    for (int i = 0; i < kMaxC; ++i) {
+      if (i >= count) break;
       VC& c_ = vc[i];
-      Manifold& m = man[c_.slot];
-      for (int j = 0; j < c_.pointCount; ++j) {
-        m.points[j].normalImpulse = c_.points[j].normalImpulse;
-        m.points[j].tangentImpulse = c_.points[j].tangentImpulse;
+      Manifold m = selGet(man, c_.slot);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j < c_.pointCount) {
+          m.points[j].normalImpulse = c_.points[j].normalImpulse;
+          m.points[j].tangentImpulse = c_.points[j].tangentImpulse;
+        }
       }
+      selSet(man, c_.slot, m);
     }
   }
 
   // b2PositionSolverManifold::Initialize + one b2ContactSolver position iteration (baumgarte/limit differ for TOI)
   __device__ __forceinline__ float csSolvePosition(int count, bool toiMode, int toiBody) {
     float minSeparation = 0.0f;
-    for (int i = 0; i < count; ++i) {
+#pragma unroll kU
+    for (int i = 0; i < kMaxC; ++i) {
+      if (i >= count) break;
       VC& c_ = vc[i];
-      const Manifold& m = man[c_.slot];
+      const Manifold m = selGet(man, c_.slot);
       int pA = c_.pA, pB = c_.pB;
       Vec2 localCenterA = lcOf(pA), localCenterB = lcOf(pB);
       float mA = mOf(pA), iA = iOf(pA), mB = mOf(pB), iB = iOf(pB);
@@ -753,7 +878,9 @@ struct Env {
       float aA = Pa(pA);
       Vec2 cB = Pc(pB);
       float aB = Pa(pB);
-      for (int j = 0; j < pointCount; ++j) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j >= pointCount) break;
         Transform xfA, xfB;
         xfA.q.Set(aA);
         xfB.q.Set(aB);
@@ -1026,42 +1153,59 @@ struct Env {
   //    stored state at index k-p+((velIters-1-k) mod p).  (1-ulp rounding ping-pong, period 2-4, is what keeps ~1 % of
   //    solves from ever reaching a fixed point.)
   // ------------------------------------------------------------------------------------------------
-  __device__ __forceinline__ void cycPack(uint32_t ibmask, int nic, float* dst) const {
-    int o = 0;
-    for (int i = 0; i < NB; ++i) {
-      if (!((ibmask >> i) & 1)) continue;
-      dst[o++] = pv[i].x;
-      dst[o++] = pv[i].y;
-      dst[o++] = pw[i];
-    }
-    for (int k = 0; k < nic; ++k)
-      for (int j = 0; j < 2; ++j) {
-        bool live = j < vc[k].pointCount;
-        dst[o++] = live ? vc[k].points[j].normalImpulse : 0.0f;
-        dst[o++] = live ? vc[k].points[j].tangentImpulse : 0.0f;
+  struct CycRow {
+    float v[kCycW];
+  };
+  // static layout: body i at [3*i..3*i+2] (bodies outside the island stay 0), contact k at [3*kCycNB + 4*k ..]
+  __device__ __forceinline__ void cycPack(uint32_t ibmask, int nic, CycRow& dst) const {
+#pragma unroll
+    for (int q = 0; q < kCycW; ++q) dst.v[q] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kCycNB; ++i) {
+      if ((ibmask >> i) & 1) {
+        dst.v[3 * i] = pv[i].x;
+        dst.v[3 * i + 1] = pv[i].y;
+        dst.v[3 * i + 2] = pw[i];
       }
-    for (; o < kCycW; ++o) dst[o] = 0.0f;
-  }
-  __device__ __forceinline__ void cycUnpack(uint32_t ibmask, int nic, const float* src) {
-    int o = 0;
-    for (int i = 0; i < NB; ++i) {
-      if (!((ibmask >> i) & 1)) continue;
-      pv[i].x = src[o++];
-      pv[i].y = src[o++];
-      pw[i] = src[o++];
     }
-    for (int k = 0; k < nic; ++k)
-      for (int j = 0; j < 2; ++j) {
-        if (j < vc[k].pointCount) {
-          vc[k].points[j].normalImpulse = src[o];
-          vc[k].points[j].tangentImpulse = src[o + 1];
+#pragma unroll
+    for (int k = 0; k < kCycNC; ++k) {
+      if (k < nic) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bool live = j < vc[k].pointCount;
+          dst.v[3 * kCycNB + 4 * k + 2 * j] = live ? vc[k].points[j].normalImpulse : 0.0f;
+          dst.v[3 * kCycNB + 4 * k + 2 * j + 1] = live ? vc[k].points[j].tangentImpulse : 0.0f;
         }
-        o += 2;
       }
+    }
+  }
+  __device__ __forceinline__ void cycUnpack(uint32_t ibmask, int nic, const CycRow& src) {
+#pragma unroll
+    for (int i = 0; i < kCycNB; ++i) {
+      if ((ibmask >> i) & 1) {
+        pv[i].x = src.v[3 * i];
+        pv[i].y = src.v[3 * i + 1];
+        pw[i] = src.v[3 * i + 2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kCycNC; ++k) {
+      if (k < nic) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (j < vc[k].pointCount) {
+            vc[k].points[j].normalImpulse = src.v[3 * kCycNB + 4 * k + 2 * j];
+            vc[k].points[j].tangentImpulse = src.v[3 * kCycNB + 4 * k + 2 * j + 1];
+          }
+        }
+      }
+    }
   }
   __device__ __forceinline__ void velocitySweeps(uint32_t ibmask, int nic, int nij, float h) {
     const int velIters = S->velIters;
-    bool watch = nij == 0 && nic > 0 && nic <= kCycNC && __popc(ibmask) <= kCycNB;
+    bool watch = nij == 0 && nic > 0 && nic <= kCycNC && (ibmask >> kCycNB) == 0;
+    CycRow cyc[kCycP];
     for (int it = 0; it < velIters; ++it) {
       bool changed = false;
       for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
@@ -1069,22 +1213,24 @@ struct Env {
       prof[6] += 1;
       if (!changed) break;
       if (watch && it < kCycSweeps) {
-        float cur[kCycW];
+        CycRow cur;
         cycPack(ibmask, nic, cur);
         bool found = false;
-        for (int p = 1; p <= kCycP && p <= it; ++p) {
-          const float* old = cyc[(it - p) & (kCycP - 1)];
+#pragma unroll
+        for (int p = 1; p <= kCycP; ++p) {
+          if (found || p > it) continue;
+          const CycRow old = selGet(cyc, (it - p) & (kCycP - 1));
           bool same = true;
-          for (int q = 0; q < kCycW; ++q) same = same && (old[q] == cur[q]);
+#pragma unroll
+          for (int q = 0; q < kCycW; ++q) same = same && (old.v[q] == cur.v[q]);
           if (same) {
             int r = (velIters - 1 - it) % p;
-            if (r != 0) cycUnpack(ibmask, nic, cyc[(it - p + r) & (kCycP - 1)]);
+            if (r != 0) cycUnpack(ibmask, nic, selGet(cyc, (it - p + r) & (kCycP - 1)));
             found = true;
-            break;
           }
         }
         if (found) break;
-        for (int q = 0; q < kCycW; ++q) cyc[it & (kCycP - 1)][q] = cur[q];
+        selSet(cyc, it & (kCycP - 1), cur);
       }
     }
   }
@@ -1195,9 +1341,31 @@ struct Env {
 
   // b2World::Solve
   __device__ __forceinline__ void solve(float h, float dtRatio) {
+    if constexpr (NB == 1) {
+      // single dynamic body: the only possible island is {body 0} with its touching contacts in contact-list order
+      for (int k = 0; k < nc; ++k) pflags.clearBits(wl.get(k), PF_ISLAND);
+      if (awakeDyn(0)) {
+        int nic = 0;
+        for (int k = 0; k < nc; ++k) {
+          int s = wl.get(k);
+          int fl = pflags.get(s);
+          if (!(fl & PF_ENABLED) || !(fl & PF_TOUCHING)) continue;
+          if (nic == kMaxC) {
+            fault |= FAULT_OVERFLOW;
+            continue;
+          }
+          ic.set(nic++, s);
+          pflags.set(s, fl | PF_ISLAND);
+        }
+        islandSolve(1u, nic, 0, h, dtRatio);
+        synchronizeFixtures(0);
+      }
+      findNewContacts(false);
+      return;
+    }
     const int nb = S->nb;
     uint32_t bodyIsland = 0, jointIsland = 0;
-    for (int k = 0; k < nc; ++k) pflags[wl[k]] &= ~PF_ISLAND;
+    for (int k = 0; k < nc; ++k) pflags.clearBits(wl.get(k), PF_ISLAND);
     int stack[NB + 4];
     for (int seed = NB - 1; seed >= 0; --seed) {
       if (seed >= nb) continue;
@@ -1214,14 +1382,14 @@ struct Env {
         ibmask |= 1u << b;
         wake(p);
         for (int k = 0; k < nc; ++k) {  // contact-edge list of b == world list filtered by b (same relative order)
-          int s = wl[k];
+          int s = wl.get(k);
           int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
           if (pa_ != p && pb_ != p) continue;
-          uint8_t fl = pflags[s];
+          int fl = pflags.get(s);
           if (fl & PF_ISLAND) continue;
           if (!(fl & PF_ENABLED) || !(fl & PF_TOUCHING)) continue;
-          ic[nic++] = (uint8_t)s;
-          pflags[s] = fl | PF_ISLAND;
+          ic.set(nic++, s);
+          pflags.set(s, fl | PF_ISLAND);
           int other = pa_ == p ? pb_ : pa_;
           if (other < 4) {
             if ((wallIsland >> other) & 1) continue;
@@ -1255,6 +1423,16 @@ struct Env {
   }
 
   // ------------------------------------------------------------------------------------------------
+  template <int MAXV>
+  static __device__ __forceinline__ void toiWallRun(TOIOutput* out, Vec2 e0, Vec2 e1, float er, const Shape* shB, const Sweep& sw) {
+    TOIWall<MAXV> tw;
+    tw.A.a0 = e0;
+    tw.A.a1 = e1;
+    tw.A.radius = er;
+    tw.B.load(shB);
+    tw.run(out, sw);
+  }
+
   // b2World::SolveTOI (+ b2Island::SolveTOI).  Without bullets only dynamic-vs-wall contacts are eligible, so a TOI
   // island is one dynamic body plus the walls it touches at the time of impact.
   // ------------------------------------------------------------------------------------------------
@@ -1264,9 +1442,9 @@ struct Env {
       sw.localCenter = V2(0.0f, 0.0f);
       sw.c0 = sw.c = V2(0.0f, 0.0f);
       sw.a0 = sw.a = 0.0f;
-      sw.alpha0 = wallAlpha0[p];
+      sw.alpha0 = selGet(wallAlpha0, p < 4 ? p : 0);
     } else {
-      int i = p - 4;
+      int i = bi(p);
       sw.localCenter = lc[i];
       sw.c0 = c0[i];
       sw.c = c[i];
@@ -1294,34 +1472,33 @@ struct Env {
       if (i < nb) alpha0[i] = 0.0f;
     for (int k = 0; k < 4; ++k) wallAlpha0[k] = 0.0f;
     for (int k = 0; k < nc; ++k) {
-      int s = wl[k];
-      pflags[s] &= ~(PF_TOI | PF_ISLAND);
-      toiCount[s] = 0;
-      toi[s] = 1.0f;
+      int s = wl.get(k);
+      pflags.clearBits(s, PF_TOI | PF_ISLAND);
+      toiCount.set(s, 0);
+      selSet(toi, s, (float)(1.0f));
     }
     for (int guard = 0; guard < 64 * (NP + 1); ++guard) {
       int minSlot = -1;
       float minAlpha = 1.0f;
       for (int k = 0; k < nc; ++k) {
-        int s = wl[k];
-        uint8_t fl = pflags[s];
+        int s = wl.get(k);
+        int fl = pflags.get(s);
         if (!(fl & PF_ENABLED)) continue;
-        if (toiCount[s] > kMaxSubSteps) continue;
+        if (toiCount.get(s) > kMaxSubSteps) continue;
         float alpha = 1.0f;
         if (fl & PF_TOI) {
-          alpha = toi[s];
+          alpha = selGet(toi, s);
         } else {
           int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
           if (pa_ >= 4) continue;  // two non-bullet dynamic bodies
-          int b = pb_ - 4;
+          int b = bi(pb_);
           if (!awakeDyn(b)) continue;
           // put the sweeps onto the same time interval (the wall's alpha0 is part of the state, see b2World::SolveTOI)
-          float alpha0_ = wallAlpha0[pa_];
-          if (wallAlpha0[pa_] < alpha0[b]) {
+          float alpha0_ = selGet(wallAlpha0, pa_);
+          if (alpha0_ < alpha0[b]) {
             alpha0_ = alpha0[b];
-            wallAlpha0[pa_] = alpha0_;  // wall sweep Advance: c0 = c = 0 stays, alpha0 moves
-          } else if (alpha0[b] < wallAlpha0[pa_]) {
-            alpha0_ = wallAlpha0[pa_];
+            selSet(wallAlpha0, pa_, alpha0_);  // wall sweep Advance: c0 = c = 0 stays, alpha0 moves
+          } else if (alpha0[b] < alpha0_) {
             Sweep sw = sweepOf(pb_);
             sw.Advance(alpha0_);
             c0[b] = sw.c0;
@@ -1330,19 +1507,22 @@ struct Env {
           }
           TOIOutput output;
           {
-            TOIWall<kShapeVerts> tw;  // wall edge vs moving shape, everything in registers (blcd_toi_wall.h)
-            tw.A.a0 = S->wallShape[pa_].v[0];
-            tw.A.a1 = S->wallShape[pa_].v[1];
-            tw.A.radius = S->wallShape[pa_].radius;
-            tw.B.load(shapeOf(pb_));
-            tw.run(&output, sweepOf(pb_));
+            // wall edge vs moving shape, everything in registers (blcd_toi_wall.h); the proxy width follows the shape so
+            // that circles and boxes do not pay for 8-vertex select chains
+            const Shape* shB = shapeOf(pb_);
+            const Vec2 e0 = S->wallShape[pa_].v[0], e1 = S->wallShape[pa_].v[1];
+            const float er = S->wallShape[pa_].radius;
+            const int nv = shB->type == kCircle ? 1 : shB->count;
+            if (nv == 1) toiWallRun<1>(&output, e0, e1, er, shB, sweepOf(pb_));
+            else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
+            else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
           }
           prof[4] += 1;
           float beta = output.t;
           if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
           else alpha = 1.0f;
-          toi[s] = alpha;
-          pflags[s] = fl | PF_TOI;
+          selSet(toi, s, (float)(alpha));
+          pflags.set(s, fl | PF_TOI);
         }
         if (alpha < minAlpha) {
           minSlot = s;
@@ -1353,20 +1533,20 @@ struct Env {
 
       const int wA = S->pairs[minSlot].a;      // wall (fixture A)
       const int pB = S->pairs[minSlot].b;
-      const int b = pB - 4;
+      const int b = bi(pB);
       // backups
-      float backupWallAlpha = wallAlpha0[wA];
+      float backupWallAlpha = selGet(wallAlpha0, wA);
       Vec2 bc0 = c0[b], bc = c[b];
       float ba0 = a0[b], ba = a[b], balpha0 = alpha0[b];
       // bA->Advance(minAlpha) for the wall, bB->Advance(minAlpha)
-      wallAlpha0[wA] = minAlpha;
+      selSet(wallAlpha0, wA, minAlpha);
       advanceBody(b, minAlpha);
       updateContact(minSlot);
-      pflags[minSlot] &= ~PF_TOI;
-      ++toiCount[minSlot];
-      if (!(pflags[minSlot] & PF_ENABLED) || !(pflags[minSlot] & PF_TOUCHING)) {
-        pflags[minSlot] &= ~PF_ENABLED;
-        wallAlpha0[wA] = backupWallAlpha;
+      pflags.clearBits(minSlot, PF_TOI);
+      toiCount.set(minSlot, toiCount.get(minSlot) + 1);
+      if (!(pflags.get(minSlot) & PF_ENABLED) || !(pflags.get(minSlot) & PF_TOUCHING)) {
+        pflags.clearBits(minSlot, PF_ENABLED);
+        selSet(wallAlpha0, wA, backupWallAlpha);
         c0[b] = bc0;
         c[b] = bc;
         a0[b] = ba0;
@@ -1381,25 +1561,30 @@ struct Env {
       // build the TOI island: contact list of the dynamic body, static others only
       uint32_t wallIsland = 1u << wA;
       int nic = 0;
-      ic[nic++] = (uint8_t)minSlot;
-      pflags[minSlot] |= PF_ISLAND;
+      ic.set(nic++, minSlot);
+      pflags.orBits(minSlot, PF_ISLAND);
       for (int k = 0; k < nc; ++k) {
         if (nic == kMaxTOIContacts) break;
-        int s = wl[k];
+        int s = wl.get(k);
         int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
         if (pa_ != pB && pb_ != pB) continue;
-        if (pflags[s] & PF_ISLAND) continue;
+        if (pflags.get(s) & PF_ISLAND) continue;
         int other = pa_ == pB ? pb_ : pa_;
         if (other >= 4) continue;  // only static (no bullets)
-        float backup = wallAlpha0[other];
-        if (!((wallIsland >> other) & 1)) wallAlpha0[other] = minAlpha;  // other->Advance(minAlpha)
+        float backup = selGet(wallAlpha0, other);
+        if (!((wallIsland >> other) & 1)) selSet(wallAlpha0, other, minAlpha);  // other->Advance(minAlpha)
         updateContact(s);
-        if (!(pflags[s] & PF_ENABLED) || !(pflags[s] & PF_TOUCHING)) {
-          wallAlpha0[other] = backup;
+        if (!(pflags.get(s) & PF_ENABLED) || !(pflags.get(s) & PF_TOUCHING)) {
+          selSet(wallAlpha0, other, backup);
           continue;
         }
-        pflags[s] |= PF_ISLAND;
-        ic[nic++] = (uint8_t)s;
+        if (nic == kMaxC) {  // only reachable in the reduced-capacity one-body configuration
+          fault |= FAULT_OVERFLOW;
+          selSet(wallAlpha0, other, backup);
+          continue;
+        }
+        pflags.orBits(s, PF_ISLAND);
+        ic.set(nic++, s);
         wallIsland |= 1u << other;
       }
       // b2Island::SolveTOI
@@ -1426,8 +1611,8 @@ struct Env {
       // reset island flags, synchronize the broad phase, invalidate the body's contact TOIs
       synchronizeFixtures(b);
       for (int k = 0; k < nc; ++k) {
-        int s = wl[k];
-        if (S->pairs[s].a == pB || S->pairs[s].b == pB) pflags[s] &= ~(PF_TOI | PF_ISLAND);
+        int s = wl.get(k);
+        if (S->pairs[s].a == pB || S->pairs[s].b == pB) pflags.clearBits(s, PF_TOI | PF_ISLAND);
       }
       findNewContacts(false);
       if (profOn) prof[3] += __builtin_amdgcn_s_memtime() - e0_;
