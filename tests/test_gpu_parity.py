@@ -64,14 +64,16 @@ def test_render_poses_equals_oracle_and_pillow(name, variant):
 def test_gif_sequences_on_device():
   """The reference's published Dropbox/Bounce LCD sequences, reproduced by the HIP path itself."""
   gifs = np.load('tests/golden/gif_lcd_frames.npz')
-  for name, pose, T in [('Dropbox', [1.66, 4.015, 1.315], 26), ('Bounce', [1.55, 4.17, 0.0], 50)]:
+  for name, key, pose, T in [('Dropbox', 'Dropbox', [[1.66, 4.015, 1.315]], 26), ('Bounce', 'Bounce', [[1.55, 4.17, 0.0]], 50),
+                             ('Bounce2', 'Bounce2', [[1.60323, 4.17499, 0.0], [2.47265, 3.01481, 0.0]], 50),
+                             ('Object2', 'Object2_circles', [[3.7294, 2.56002, 0.0], [3.58992, 0.70644, 0.0]], 50)]:
     env = getattr(B.envs, name)()
     h = Handle(env.scene.desc, 1, 0)
-    h.reset(None, np.array([[pose]], np.float32), None)
+    h.reset(None, np.array([pose], np.float32), None)
     lcd = np.zeros((T, 1, 16, 16), np.uint8)
     h.rollout(None, T, lcd_out=lcd)
-    exp = np.unpackbits(gifs[name], axis=-1)[:, :, :16]
-    assert (lcd[:, 0] == exp).all(), name
+    exp = np.unpackbits(gifs[key], axis=-1)[:, :, :16]
+    assert (lcd[:, 0] == exp).all(), key
     h.close()
 
 

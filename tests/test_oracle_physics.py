@@ -36,6 +36,34 @@ def test_bounce_gif_all_50_frames(oracle):
     assert (o.render() == gif[t]).all(), f'frame {t}'
 
 
+@pytest.mark.parametrize('env_name,key,start', [
+    ('Bounce2', 'Bounce2', [[1.60323, 4.17499, 0.0], [2.47265, 3.01481, 0.0]]),
+    ('Object2', 'Object2_circles', [[3.7294, 2.56002, 0.0], [3.58992, 0.70644, 0.0]]),
+])
+def test_two_ball_gifs_all_50_frames(oracle, env_name, key, start):
+  """Reference output pin for dynamic-vs-dynamic contacts: assets/envs/Bounce2.gif (ball-ball contact touching at frames 7 and
+  33-38, fitted by tools/fit_gif_two_bodies.py) and Object2-circles.gif.  b2CollideCircles, two-body islands, creation-order
+  dependent Gauss-Seidel: swapping the two start poses does NOT reproduce Bounce2.gif."""
+  gif = _gif(key, 16)
+  env = getattr(B.envs, env_name)()
+  o = oracle.OracleEnv(env.scene.desc)
+  o.reset(np.asarray(start, np.float32), [0, 0])
+  touched = False
+  for t in range(50):
+    o.step(np.zeros(1, np.float32))
+    assert (o.render() == gif[t]).all(), f'frame {t}'
+    touched = touched or o.dump()[2][8, 1] > 0
+  if key == 'Bounce2':
+    assert touched
+    o2 = oracle.OracleEnv(env.scene.desc)
+    o2.reset(np.asarray(start[::-1], np.float32), [0, 0])
+    bad = 0
+    for t in range(50):
+      o2.step(np.zeros(1, np.float32))
+      bad += int((o2.render() != gif[t]).sum())
+    assert bad > 0
+
+
 def test_free_fall_increments(oracle):
   """Semi-implicit Euler, 3 sub-steps of 1/30 s: env-step k moves by -(g/900)(9k-3)."""
   _, o = _env(oracle, 'Dropbox', [[2.5, 3.6, 0.3]])
