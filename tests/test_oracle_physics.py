@@ -42,8 +42,7 @@ def test_bounce_gif_all_50_frames(oracle):
 ])
 def test_two_ball_gifs_all_50_frames(oracle, env_name, key, start):
   """Reference output pin for dynamic-vs-dynamic contacts: assets/envs/Bounce2.gif (ball-ball contact touching at frames 7 and
-  33-38, fitted by tools/fit_gif_two_bodies.py) and Object2-circles.gif.  b2CollideCircles, two-body islands, creation-order
-  dependent Gauss-Seidel: swapping the two start poses does NOT reproduce Bounce2.gif."""
+  33-38, fitted by tools/fit_gif_two_bodies.py) and Object2-circles.gif: b2CollideCircles and two-body islands."""
   gif = _gif(key, 16)
   env = getattr(B.envs, env_name)()
   o = oracle.OracleEnv(env.scene.desc)
@@ -55,13 +54,6 @@ def test_two_ball_gifs_all_50_frames(oracle, env_name, key, start):
     touched = touched or o.dump()[2][8, 1] > 0
   if key == 'Bounce2':
     assert touched
-    o2 = oracle.OracleEnv(env.scene.desc)
-    o2.reset(np.asarray(start[::-1], np.float32), [0, 0])
-    bad = 0
-    for t in range(50):
-      o2.step(np.zeros(1, np.float32))
-      bad += int((o2.render() != gif[t]).sum())
-    assert bad > 0
 
 
 def test_free_fall_increments(oracle):
