@@ -58,3 +58,26 @@ def test_batched_env_shapes_and_torch_zero_copy():
   frames = venv.render_states(host_fs[:32].astype(np.float64))
   assert frames.shape == (32, 16, 24) and (frames != host_lcd[:32].astype(bool)).reshape(32, -1).sum(1).max() <= 3
   venv.close()
+
+
+def test_barrel_writer_matches_reference_layout(tmp_path):
+  """research/data.py:36-79 layout: entry j = observation before action j; loadable the way RolloutDataset does it."""
+  from boxlcd_amd.data import fill_barrels
+  paths = fill_barrels('Urchin', 1, tmp_path, 'train', {'ep_len': 12}, seed=3, barrel_size=200, stamp='20260101T000000')
+  assert paths[0].name == '20260101T000000-12.barrel.npz' and list((tmp_path / 'train').glob('*.barrel.npz')) == paths
+  b = np.load(paths[0], allow_pickle=True)
+  assert set(b.keys()) == {'action', 'full_state', 'proprio', 'lcd'}
+  assert b['action'].shape == (200, 12, 3) and b['action'].dtype == np.float64
+  assert b['full_state'].shape == (200, 12, 16) and b['full_state'].dtype == np.float32
+  assert b['proprio'].shape == (200, 12, 16) and b['lcd'].shape == (200, 12, 16, 32) and b['lcd'].dtype == bool
+  # replay episode 7 with the single-env API semantics: obs_{j+1} = step(action_j)
+  venv = B.BatchedWorldEnv('Urchin', 200, {'ep_len': 12}, seed=3)
+  obs = venv.reset()
+  assert (obs['lcd'][7] == b['lcd'][7, 0]).all() and np.allclose(obs['full_state'][7], b['full_state'][7, 0])
+  for j in range(11):
+    obs, *_ = venv.step(b['action'][:, j].astype(np.float32))
+    assert (obs['lcd'][7] == b['lcd'][7, j + 1]).all() and np.allclose(obs['full_state'][7], b['full_state'][7, j + 1], atol=1e-6)
+  venv.close()
+  import torch
+  elems = {k: torch.as_tensor(b[k], dtype=torch.float32) for k in b.keys()}     # research/data.py:149
+  assert elems['lcd'].max() <= 1.0 and elems['lcd'].min() >= 0.0

@@ -56,6 +56,23 @@ def test_two_ball_gifs_all_50_frames(oracle, env_name, key, start):
     assert touched
 
 
+def test_box_and_ball_gif_near_pin(oracle):
+  """assets/envs/Object2.gif (a box and a ball, both e=0.8; same seed as Bounce2.gif, so the same start positions): the box
+  hits the ball in flight at frame 7 (b2CollidePolygonAndCircle), bounces and tumbles on two-point manifolds with
+  restitution.  Frames 0-23 are reproduced exactly and 99.9 % of all pixels (13 px differ over frames 24-41) - the
+  residual is chaotic sensitivity to the start pose, which tools/fit_gif_*.py could not resolve further."""
+  gif = _gif('Object2', 16)
+  env = B.envs.Object2()
+  o = oracle.OracleEnv(env.scene.desc)
+  o.reset(np.array([[1.6007380460248897, 4.179611249962136, 1.3021202141667423], [2.4754642156346462, 3.016491870676103, 0.0]], np.float32), [1, 0])
+  bad, touched = [], False
+  for t in range(50):
+    o.step(np.zeros(1, np.float32))
+    bad.append(int((o.render() != gif[t]).sum()))
+    touched = touched or o.dump()[2][8, 1] > 0
+  assert touched and sum(bad[:24]) == 0 and sum(bad) <= 13, bad
+
+
 def test_free_fall_increments(oracle):
   """Semi-implicit Euler, 3 sub-steps of 1/30 s: env-step k moves by -(g/900)(9k-3)."""
   _, o = _env(oracle, 'Dropbox', [[2.5, 3.6, 0.3]])
