@@ -1,0 +1,688 @@
+// blcd_island_reg.h — register-resident b2Island::Solve for small islands (<= NJR joints, <= NCR contacts).
+//
+// The 540 Gauss-Seidel velocity sweeps per env step are the hot loop of the path (b2Island::Solve,
+// b2ContactSolver::SolveVelocityConstraints, b2RevoluteJoint::SolveVelocityConstraints; reference call site
+// boxLCD/world_env.py:448-450).  In the generic Env the constraint arrays are indexed with run-time values (island order is
+// dynamic), which keeps them in scratch: measured 27 k cycles per sweep for an Urchin (3 joints + ~3 contacts).  Here the
+// island's working set is staged once per world step into statically indexed structures, in island (DFS) order, so that
+// the sweeps run entirely out of VGPRs:
+//   * constraints k = 0..n-1 are unrolled (static index), each remembers its two body ids;
+//   * body velocities/positions are small arrays read/written through compare-select chains on the body id.
+// Arithmetic and operation order are exactly those of the generic path (and of Box2D); the parity tests compare both
+// against the CPU oracle.  Islands that do not fit fall back to the generic path.
+#pragma once
+#include "blcd_collide.h"
+
+namespace blcd {
+
+// always-select array access (compile-time unrolled word selects; see selGet in blcd_world.h for why not a loop)
+template <typename T, int N, size_t... K>
+__device__ __forceinline__ void rWordsGet(const T (&a)[N], int i, int t, uint32_t* r, std::index_sequence<K...>) {
+  uint32_t w[sizeof...(K)];
+  __builtin_memcpy(w, &a[t], sizeof(T));
+  ((r[K] = (i == t) ? w[K] : r[K]), ...);
+}
+template <typename T, int N, size_t... Ts>
+__device__ __forceinline__ T rGetImpl(const T (&a)[N], int i, std::index_sequence<Ts...>) {
+  constexpr size_t W = sizeof(T) / 4;
+  uint32_t r[W];
+  __builtin_memcpy(r, &a[0], sizeof(T));
+  (rWordsGet(a, i, (int)(Ts + 1), r, std::make_index_sequence<W>{}), ...);
+  T out;
+  __builtin_memcpy(&out, r, sizeof(T));
+  return out;
+}
+template <int N, typename T>
+__device__ __forceinline__ T rGet(const T (&a)[N], int i) {
+  return rGetImpl(a, i, std::make_index_sequence<N - 1>{});
+}
+template <typename T, int N, size_t... K>
+__device__ __forceinline__ void rWordsSet(T (&a)[N], int i, int t, const uint32_t* v, std::index_sequence<K...>) {
+  uint32_t w[sizeof...(K)];
+  __builtin_memcpy(w, &a[t], sizeof(T));
+  ((w[K] = (i == t) ? v[K] : w[K]), ...);
+  __builtin_memcpy(&a[t], w, sizeof(T));
+}
+template <typename T, int N, size_t... Ts>
+__device__ __forceinline__ void rSetImpl(T (&a)[N], int i, const T& val, std::index_sequence<Ts...>) {
+  constexpr size_t W = sizeof(T) / 4;
+  uint32_t v[W];
+  __builtin_memcpy(v, &val, sizeof(T));
+  (rWordsSet(a, i, (int)Ts, v, std::make_index_sequence<W>{}), ...);
+}
+template <int N, typename T>
+__device__ __forceinline__ void rSet(T (&a)[N], int i, const T& v) {
+  rSetImpl(a, i, v, std::make_index_sequence<N>{});
+}
+
+struct BodyVel {
+  Vec2 v;
+  float w;
+};
+struct BodyPos {
+  Vec2 c;
+  float a;
+};
+struct BodyMass {
+  float invMass, invI;
+  Vec2 lc;
+};
+
+struct RJoint {  // one revolute joint in island order
+  int A, B;      // dynamic-body indices
+  Vec2 anchorA, anchorB;
+  int enableLimit;
+  float lower, upper, maxMotorTorque, ref, speed;
+  Vec3 imp;
+  float motor;
+  int limit;
+  Vec2 rA, rB;
+  Mat33 mass;
+  float motorMass;
+};
+
+struct RPoint {
+  Vec2 rA, rB;
+  float normalImpulse, tangentImpulse, normalMass, tangentMass, velocityBias;
+};
+struct RContact {  // velocity + position constraint of one contact in island order
+  RPoint points[2];
+  Vec2 normal;
+  Mat22 normalMass, K;
+  int pA, pB;  // proxy ids (0..3 walls, 4+i bodies)
+  float friction, restitution;
+  int pointCount;
+  // position constraint (copy of the manifold: b2ContactPositionConstraint)
+  int mtype, mcount;
+  Vec2 localNormal, localPoint, lp0, lp1;
+  float radiusA, radiusB;
+};
+
+template <int NB, int NJR, int NCR>
+struct RegIsland {
+  BodyVel vel[NB];
+  BodyPos pos[NB];
+  BodyMass mass[NB];
+  RJoint jt[NJR > 0 ? NJR : 1];
+  RContact ct[NCR];
+  int nj, nc;
+
+  // ---- body accessors by proxy id ----
+  __device__ __forceinline__ BodyVel V(int p) const {
+    BodyVel z;
+    z.v = V2(0.0f, 0.0f);
+    z.w = 0.0f;
+    BodyVel r = rGet(vel, p < 4 ? 0 : p - 4);
+    return p < 4 ? z : r;
+  }
+  __device__ __forceinline__ void setV(int p, const BodyVel& x) {
+    if (p >= 4) rSet(vel, p - 4, x);
+  }
+  __device__ __forceinline__ BodyPos P(int p) const {
+    BodyPos z;
+    z.c = V2(0.0f, 0.0f);
+    z.a = 0.0f;
+    BodyPos r = rGet(pos, p < 4 ? 0 : p - 4);
+    return p < 4 ? z : r;
+  }
+  __device__ __forceinline__ void setP(int p, const BodyPos& x) {
+    if (p >= 4) rSet(pos, p - 4, x);
+  }
+  __device__ __forceinline__ BodyMass M(int p) const {
+    BodyMass z;
+    z.invMass = 0.0f;
+    z.invI = 0.0f;
+    z.lc = V2(0.0f, 0.0f);
+    BodyMass r = rGet(mass, p < 4 ? 0 : p - 4);
+    return p < 4 ? z : r;
+  }
+
+  // ---- b2ContactSolver::InitializeVelocityConstraints for contact k (k static) ----
+  __device__ __forceinline__ void initContact(RContact& c_, const Manifold& manifold) {
+    const int pA = c_.pA, pB = c_.pB;
+    BodyMass mAs = M(pA), mBs = M(pB);
+    float mA = mAs.invMass, mB = mBs.invMass, iA = mAs.invI, iB = mBs.invI;
+    BodyPos pa_ = P(pA), pb_ = P(pB);
+    BodyVel va_ = V(pA), vb_ = V(pB);
+    Vec2 cA = pa_.c, cB = pb_.c, vA = va_.v, vB = vb_.v;
+    float aA = pa_.a, aB = pb_.a, wA = va_.w, wB = vb_.w;
+    Transform xfA, xfB;
+    xfA.q.Set(aA);
+    xfB.q.Set(aB);
+    xfA.p = cA - Mul(xfA.q, mAs.lc);
+    xfB.p = cB - Mul(xfB.q, mBs.lc);
+    WorldManifold worldManifold;
+    worldManifold.Initialize(&manifold, xfA, c_.radiusA, xfB, c_.radiusB);
+    c_.normal = worldManifold.normal;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j >= c_.pointCount) break;
+      RPoint* vcp = c_.points + j;
+      vcp->rA = worldManifold.points[j] - cA;
+      vcp->rB = worldManifold.points[j] - cB;
+      float rnA = Cross(vcp->rA, c_.normal);
+      float rnB = Cross(vcp->rB, c_.normal);
+      float kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+      vcp->normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+      Vec2 tangent = Cross(c_.normal, 1.0f);
+      float rtA = Cross(vcp->rA, tangent);
+      float rtB = Cross(vcp->rB, tangent);
+      float kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+      vcp->tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+      vcp->velocityBias = 0.0f;
+      float vRel = Dot(c_.normal, vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA));
+      if (vRel < -kVelocityThreshold) vcp->velocityBias = -c_.restitution * vRel;
+    }
+    if (c_.pointCount == 2) {
+      RPoint* vcp1 = c_.points + 0;
+      RPoint* vcp2 = c_.points + 1;
+      float rn1A = Cross(vcp1->rA, c_.normal);
+      float rn1B = Cross(vcp1->rB, c_.normal);
+      float rn2A = Cross(vcp2->rA, c_.normal);
+      float rn2B = Cross(vcp2->rB, c_.normal);
+      float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
+      float k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+      float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+      const float k_maxConditionNumber = 1000.0f;
+      if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
+        c_.K.ex = V2(k11, k12);
+        c_.K.ey = V2(k12, k22);
+        c_.normalMass = c_.K.GetInverse();
+      } else {
+        c_.pointCount = 1;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void warmStartContact(RContact& c_) {
+    const int pA = c_.pA, pB = c_.pB;
+    BodyMass mAs = M(pA), mBs = M(pB);
+    float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
+    BodyVel va_ = V(pA), vb_ = V(pB);
+    Vec2 vA = va_.v, vB = vb_.v;
+    float wA = va_.w, wB = vb_.w;
+    Vec2 normal = c_.normal;
+    Vec2 tangent = Cross(normal, 1.0f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j >= c_.pointCount) break;
+      RPoint* vcp = c_.points + j;
+      Vec2 P_ = vcp->normalImpulse * normal + vcp->tangentImpulse * tangent;
+      wA -= iA * Cross(vcp->rA, P_);
+      vA -= mA * P_;
+      wB += iB * Cross(vcp->rB, P_);
+      vB += mB * P_;
+    }
+    va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
+    setV(pA, va_);
+    setV(pB, vb_);
+  }
+
+  // b2ContactSolver::SolveVelocityConstraints for one contact; returns true iff a non-zero impulse was applied
+  __device__ __forceinline__ bool sweepContact(RContact& c_) {
+    bool changed = false;
+    const int pA = c_.pA, pB = c_.pB;
+    BodyMass mAs = M(pA), mBs = M(pB);
+    float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
+    int pointCount = c_.pointCount;
+    BodyVel va_ = V(pA), vb_ = V(pB);
+    Vec2 vA = va_.v, vB = vb_.v;
+    float wA = va_.w, wB = vb_.w;
+    Vec2 normal = c_.normal;
+    Vec2 tangent = Cross(normal, 1.0f);
+    float friction = c_.friction;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j >= pointCount) break;
+      RPoint* vcp = c_.points + j;
+      Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+      float vt = Dot(dv, tangent) - 0.0f;
+      float lambda = vcp->tangentMass * (-vt);
+      float maxFriction = friction * vcp->normalImpulse;
+      float newImpulse = Clamp(vcp->tangentImpulse + lambda, -maxFriction, maxFriction);
+      lambda = newImpulse - vcp->tangentImpulse;
+      vcp->tangentImpulse = newImpulse;
+      changed = changed || (lambda != 0.0f);
+      Vec2 P_ = lambda * tangent;
+      vA -= mA * P_;
+      wA -= iA * Cross(vcp->rA, P_);
+      vB += mB * P_;
+      wB += iB * Cross(vcp->rB, P_);
+    }
+    if (pointCount == 1) {
+      RPoint* vcp = c_.points + 0;
+      Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+      float vn = Dot(dv, normal);
+      float lambda = -vcp->normalMass * (vn - vcp->velocityBias);
+      float newImpulse = Max(vcp->normalImpulse + lambda, 0.0f);
+      lambda = newImpulse - vcp->normalImpulse;
+      vcp->normalImpulse = newImpulse;
+      changed = changed || (lambda != 0.0f);
+      Vec2 P_ = lambda * normal;
+      vA -= mA * P_;
+      wA -= iA * Cross(vcp->rA, P_);
+      vB += mB * P_;
+      wB += iB * Cross(vcp->rB, P_);
+    } else {
+      RPoint* cp1 = c_.points + 0;
+      RPoint* cp2 = c_.points + 1;
+      Vec2 a_ = V2(cp1->normalImpulse, cp2->normalImpulse);
+      Vec2 dv1 = vB + Cross(wB, cp1->rB) - vA - Cross(wA, cp1->rA);
+      Vec2 dv2 = vB + Cross(wB, cp2->rB) - vA - Cross(wA, cp2->rA);
+      float vn1 = Dot(dv1, normal);
+      float vn2 = Dot(dv2, normal);
+      Vec2 b;
+      b.x = vn1 - cp1->velocityBias;
+      b.y = vn2 - cp2->velocityBias;
+      b -= Mul(c_.K, a_);
+      Vec2 x;
+      bool solved = false;
+      x = -Mul(c_.normalMass, b);
+      if (x.x >= 0.0f && x.y >= 0.0f) solved = true;
+      if (!solved) {
+        x.x = -cp1->normalMass * b.x;
+        x.y = 0.0f;
+        vn2 = c_.K.ex.y * x.x + b.y;
+        if (x.x >= 0.0f && vn2 >= 0.0f) solved = true;
+      }
+      if (!solved) {
+        x.x = 0.0f;
+        x.y = -cp2->normalMass * b.y;
+        vn1 = c_.K.ey.x * x.y + b.x;
+        if (x.y >= 0.0f && vn1 >= 0.0f) solved = true;
+      }
+      if (!solved) {
+        x.x = 0.0f;
+        x.y = 0.0f;
+        vn1 = b.x;
+        vn2 = b.y;
+        if (vn1 >= 0.0f && vn2 >= 0.0f) solved = true;
+      }
+      if (solved) {
+        Vec2 d = x - a_;
+        changed = changed || (d.x != 0.0f) || (d.y != 0.0f);
+        Vec2 P1 = d.x * normal;
+        Vec2 P2 = d.y * normal;
+        vA -= mA * (P1 + P2);
+        wA -= iA * (Cross(cp1->rA, P1) + Cross(cp2->rA, P2));
+        vB += mB * (P1 + P2);
+        wB += iB * (Cross(cp1->rB, P1) + Cross(cp2->rB, P2));
+        cp1->normalImpulse = x.x;
+        cp2->normalImpulse = x.y;
+      }
+    }
+    va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
+    setV(pA, va_);
+    setV(pB, vb_);
+    return changed;
+  }
+
+  // b2PositionSolverManifold + one b2ContactSolver::SolvePositionConstraints pass over one contact; returns min separation
+  __device__ __forceinline__ float positionContact(const RContact& c_, float minSeparation) {
+    const int pA = c_.pA, pB = c_.pB;
+    BodyMass mAs = M(pA), mBs = M(pB);
+    float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
+    Vec2 localCenterA = mAs.lc, localCenterB = mBs.lc;
+    float radiusA = c_.radiusA, radiusB = c_.radiusB;
+    BodyPos pa_ = P(pA), pb_ = P(pB);
+    Vec2 cA = pa_.c, cB = pb_.c;
+    float aA = pa_.a, aB = pb_.a;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j >= c_.mcount) break;
+      Transform xfA, xfB;
+      xfA.q.Set(aA);
+      xfB.q.Set(aB);
+      xfA.p = cA - Mul(xfA.q, localCenterA);
+      xfB.p = cB - Mul(xfB.q, localCenterB);
+      Vec2 normal, point;
+      float separation;
+      Vec2 lpj = j == 0 ? c_.lp0 : c_.lp1;
+      if (c_.mtype == kManifoldCircles) {
+        Vec2 pointA = Mul(xfA, c_.localPoint);
+        Vec2 pointB = Mul(xfB, c_.lp0);
+        normal = pointB - pointA;
+        Normalize(normal);
+        point = 0.5f * (pointA + pointB);
+        separation = Dot(pointB - pointA, normal) - radiusA - radiusB;
+      } else if (c_.mtype == kManifoldFaceA) {
+        normal = Mul(xfA.q, c_.localNormal);
+        Vec2 planePoint = Mul(xfA, c_.localPoint);
+        Vec2 clipPoint = Mul(xfB, lpj);
+        separation = Dot(clipPoint - planePoint, normal) - radiusA - radiusB;
+        point = clipPoint;
+      } else {
+        normal = Mul(xfB.q, c_.localNormal);
+        Vec2 planePoint = Mul(xfB, c_.localPoint);
+        Vec2 clipPoint = Mul(xfA, lpj);
+        separation = Dot(clipPoint - planePoint, normal) - radiusA - radiusB;
+        point = clipPoint;
+        normal = -normal;
+      }
+      Vec2 rA = point - cA;
+      Vec2 rB = point - cB;
+      minSeparation = Min(minSeparation, separation);
+      float C = Clamp(kBaumgarte * (separation + kLinearSlop), -kMaxLinearCorrection, 0.0f);
+      float rnA = Cross(rA, normal);
+      float rnB = Cross(rB, normal);
+      float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+      float impulse = K > 0.0f ? -C / K : 0.0f;
+      Vec2 P_ = impulse * normal;
+      cA -= mA * P_;
+      aA -= iA * Cross(rA, P_);
+      cB += mB * P_;
+      aB += iB * Cross(rB, P_);
+    }
+    pa_.c = cA; pa_.a = aA; pb_.c = cB; pb_.a = aB;
+    setP(pA, pa_);
+    setP(pB, pb_);
+    return minSeparation;
+  }
+
+  // ---- b2RevoluteJoint ----
+  __device__ __forceinline__ void initJoint(RJoint& J, float dtRatio) {
+    BodyMass mAs = rGet(mass, J.A), mBs = rGet(mass, J.B);
+    BodyPos pa_ = rGet(pos, J.A), pb_ = rGet(pos, J.B);
+    BodyVel va_ = rGet(vel, J.A), vb_ = rGet(vel, J.B);
+    float aA = pa_.a, aB = pb_.a;
+    Vec2 vA = va_.v, vB = vb_.v;
+    float wA = va_.w, wB = vb_.w;
+    Rot qA = MakeRot(aA), qB = MakeRot(aB);
+    J.rA = Mul(qA, J.anchorA - mAs.lc);
+    J.rB = Mul(qB, J.anchorB - mBs.lc);
+    Vec2 rA = J.rA, rB = J.rB;
+    float mA = mAs.invMass, mB = mBs.invMass, iA = mAs.invI, iB = mBs.invI;
+    bool fixedRotation = (iA + iB == 0.0f);
+    Mat33& Mx = J.mass;
+    Mx.ex.x = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+    Mx.ey.x = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+    Mx.ez.x = -rA.y * iA - rB.y * iB;
+    Mx.ex.y = Mx.ey.x;
+    Mx.ey.y = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+    Mx.ez.y = rA.x * iA + rB.x * iB;
+    Mx.ex.z = Mx.ez.x;
+    Mx.ey.z = Mx.ez.y;
+    Mx.ez.z = iA + iB;
+    float motorMass = iA + iB;
+    if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
+    J.motorMass = motorMass;
+    if (fixedRotation) J.motor = 0.0f;
+    if (J.enableLimit && fixedRotation == false) {
+      float jointAngle = aB - aA - J.ref;
+      if (Abs(J.upper - J.lower) < 2.0f * kAngularSlop) {
+        J.limit = 3;
+      } else if (jointAngle <= J.lower) {
+        if (J.limit != 1) J.imp.z = 0.0f;
+        J.limit = 1;
+      } else if (jointAngle >= J.upper) {
+        if (J.limit != 2) J.imp.z = 0.0f;
+        J.limit = 2;
+      } else {
+        J.limit = 0;
+        J.imp.z = 0.0f;
+      }
+    } else {
+      J.limit = 0;
+    }
+    // warm starting is always on in b2World::Step
+    J.imp *= dtRatio;
+    J.motor *= dtRatio;
+    Vec2 P_ = V2(J.imp.x, J.imp.y);
+    vA -= mA * P_;
+    wA -= iA * (Cross(rA, P_) + J.motor + J.imp.z);
+    vB += mB * P_;
+    wB += iB * (Cross(rB, P_) + J.motor + J.imp.z);
+    va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
+    rSet(vel, J.A, va_);
+    rSet(vel, J.B, vb_);
+  }
+
+  __device__ __forceinline__ bool sweepJoint(RJoint& J, float dt) {
+    bool changed = false;
+    BodyMass mAs = rGet(mass, J.A), mBs = rGet(mass, J.B);
+    BodyVel va_ = rGet(vel, J.A), vb_ = rGet(vel, J.B);
+    Vec2 vA = va_.v, vB = vb_.v;
+    float wA = va_.w, wB = vb_.w;
+    float mA = mAs.invMass, mB = mBs.invMass, iA = mAs.invI, iB = mBs.invI;
+    Vec2 rA = J.rA, rB = J.rB;
+    const Mat33& Mx = J.mass;
+    bool fixedRotation = (iA + iB == 0.0f);
+    int limitState = J.limit;
+    if (limitState != 3 && fixedRotation == false) {
+      float Cdot = wB - wA - J.speed;
+      float impulse = -J.motorMass * Cdot;
+      float oldImpulse = J.motor;
+      float maxImpulse = dt * J.maxMotorTorque;
+      J.motor = Clamp(J.motor + impulse, -maxImpulse, maxImpulse);
+      impulse = J.motor - oldImpulse;
+      changed = changed || (impulse != 0.0f);
+      wA -= iA * impulse;
+      wB += iB * impulse;
+    }
+    if (J.enableLimit && limitState != 0 && fixedRotation == false) {
+      Vec2 Cdot1 = vB + Cross(wB, rB) - vA - Cross(wA, rA);
+      float Cdot2 = wB - wA;
+      Vec3 Cdot = Vec3{Cdot1.x, Cdot1.y, Cdot2};
+      Vec3 impulse = -Mx.Solve33(Cdot);
+      Vec3 acc = J.imp;
+      if (limitState == 3) {
+        acc += impulse;
+      } else if (limitState == 1) {
+        float newImpulse = acc.z + impulse.z;
+        if (newImpulse < 0.0f) {
+          Vec2 rhs = -Cdot1 + acc.z * V2(Mx.ez.x, Mx.ez.y);
+          Vec2 reduced = Mx.Solve22(rhs);
+          impulse.x = reduced.x;
+          impulse.y = reduced.y;
+          impulse.z = -acc.z;
+          acc.x += reduced.x;
+          acc.y += reduced.y;
+          acc.z = 0.0f;
+        } else {
+          acc += impulse;
+        }
+      } else if (limitState == 2) {
+        float newImpulse = acc.z + impulse.z;
+        if (newImpulse > 0.0f) {
+          Vec2 rhs = -Cdot1 + acc.z * V2(Mx.ez.x, Mx.ez.y);
+          Vec2 reduced = Mx.Solve22(rhs);
+          impulse.x = reduced.x;
+          impulse.y = reduced.y;
+          impulse.z = -acc.z;
+          acc.x += reduced.x;
+          acc.y += reduced.y;
+          acc.z = 0.0f;
+        } else {
+          acc += impulse;
+        }
+      }
+      changed = changed || (impulse.x != 0.0f) || (impulse.y != 0.0f) || (impulse.z != 0.0f) || (acc.x != J.imp.x) ||
+                (acc.y != J.imp.y) || (acc.z != J.imp.z);
+      J.imp = acc;
+      Vec2 P_ = V2(impulse.x, impulse.y);
+      vA -= mA * P_;
+      wA -= iA * (Cross(rA, P_) + impulse.z);
+      vB += mB * P_;
+      wB += iB * (Cross(rB, P_) + impulse.z);
+    } else {
+      Vec2 Cdot = vB + Cross(wB, rB) - vA - Cross(wA, rA);
+      Vec2 impulse = Mx.Solve22(-Cdot);
+      changed = changed || (impulse.x != 0.0f) || (impulse.y != 0.0f);
+      J.imp.x += impulse.x;
+      J.imp.y += impulse.y;
+      vA -= mA * impulse;
+      wA -= iA * Cross(rA, impulse);
+      vB += mB * impulse;
+      wB += iB * Cross(rB, impulse);
+    }
+    va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
+    rSet(vel, J.A, va_);
+    rSet(vel, J.B, vb_);
+    return changed;
+  }
+
+  __device__ __forceinline__ bool positionJoint(const RJoint& J) {
+    BodyMass mAs = rGet(mass, J.A), mBs = rGet(mass, J.B);
+    BodyPos pa_ = rGet(pos, J.A), pb_ = rGet(pos, J.B);
+    Vec2 cA = pa_.c, cB = pb_.c;
+    float aA = pa_.a, aB = pb_.a;
+    float mA = mAs.invMass, mB = mBs.invMass, iA = mAs.invI, iB = mBs.invI;
+    float angularError = 0.0f;
+    float positionError = 0.0f;
+    bool fixedRotation = (iA + iB == 0.0f);
+    int limitState = J.limit;
+    if (J.enableLimit && limitState != 0 && fixedRotation == false) {
+      float angle = aB - aA - J.ref;
+      float limitImpulse = 0.0f;
+      if (limitState == 3) {
+        float C = Clamp(angle - J.lower, -kMaxAngularCorrection, kMaxAngularCorrection);
+        limitImpulse = -J.motorMass * C;
+        angularError = Abs(C);
+      } else if (limitState == 1) {
+        float C = angle - J.lower;
+        angularError = -C;
+        C = Clamp(C + kAngularSlop, -kMaxAngularCorrection, 0.0f);
+        limitImpulse = -J.motorMass * C;
+      } else if (limitState == 2) {
+        float C = angle - J.upper;
+        angularError = C;
+        C = Clamp(C - kAngularSlop, 0.0f, kMaxAngularCorrection);
+        limitImpulse = -J.motorMass * C;
+      }
+      aA -= iA * limitImpulse;
+      aB += iB * limitImpulse;
+    }
+    {
+      Rot qA = MakeRot(aA), qB = MakeRot(aB);
+      Vec2 rA = Mul(qA, J.anchorA - mAs.lc);
+      Vec2 rB = Mul(qB, J.anchorB - mBs.lc);
+      Vec2 C = cB + rB - cA - rA;
+      positionError = Length(C);
+      Mat22 K;
+      K.ex.x = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
+      K.ex.y = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+      K.ey.x = K.ex.y;
+      K.ey.y = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+      Vec2 impulse = -K.Solve(C);
+      cA -= mA * impulse;
+      aA -= iA * Cross(rA, impulse);
+      cB += mB * impulse;
+      aB += iB * Cross(rB, impulse);
+    }
+    pa_.c = cA; pa_.a = aA; pb_.c = cB; pb_.a = aB;
+    rSet(pos, J.A, pa_);
+    rSet(pos, J.B, pb_);
+    return positionError <= kLinearSlop && angularError <= kAngularSlop;
+  }
+
+  // state row for the short-cycle detector (joint-free islands): all body velocities + contact impulses
+  static constexpr int kCycP = NB <= 3 ? 4 : 2;
+  static constexpr int kCycW = 3 * NB + 4 * NCR;
+  struct CycRow {
+    float v[kCycW];
+  };
+  __device__ __forceinline__ void cycPack(CycRow& r) const {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      r.v[3 * i] = vel[i].v.x;
+      r.v[3 * i + 1] = vel[i].v.y;
+      r.v[3 * i + 2] = vel[i].w;
+    }
+#pragma unroll
+    for (int k = 0; k < NCR; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bool live = k < nc && j < ct[k].pointCount;
+        r.v[3 * NB + 4 * k + 2 * j] = live ? ct[k].points[j].normalImpulse : 0.0f;
+        r.v[3 * NB + 4 * k + 2 * j + 1] = live ? ct[k].points[j].tangentImpulse : 0.0f;
+      }
+  }
+  __device__ __forceinline__ void cycUnpack(const CycRow& r) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      vel[i].v.x = r.v[3 * i];
+      vel[i].v.y = r.v[3 * i + 1];
+      vel[i].w = r.v[3 * i + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < NCR; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (k < nc && j < ct[k].pointCount) {
+          ct[k].points[j].normalImpulse = r.v[3 * NB + 4 * k + 2 * j];
+          ct[k].points[j].tangentImpulse = r.v[3 * NB + 4 * k + 2 * j + 1];
+        }
+  }
+
+  // all velocity sweeps, with the bit-safe early exits of the generic path (fixed point; short cycle for joint-free islands)
+  __device__ __forceinline__ int velocitySweeps(int velIters, float dt) {
+    int done = 0;
+    const bool watch = nj == 0 && nc > 0;
+    CycRow cyc[kCycP];
+    for (int it = 0; it < velIters; ++it) {
+      bool changed = false;
+      if constexpr (NJR > 0) {
+#pragma unroll
+        for (int k = 0; k < NJR; ++k)
+          if (k < nj) changed = sweepJoint(jt[k], dt) || changed;
+      }
+#pragma unroll
+      for (int k = 0; k < NCR; ++k)
+        if (k < nc) changed = sweepContact(ct[k]) || changed;
+      ++done;
+      if (!changed) break;
+      if (watch && it < 24) {
+        CycRow cur;
+        cycPack(cur);
+        bool found = false;
+#pragma unroll
+        for (int p = 1; p <= kCycP; ++p) {
+          if (found || p > it) continue;
+          const CycRow old = rGet(cyc, (it - p) & (kCycP - 1));
+          bool same = true;
+#pragma unroll
+          for (int q = 0; q < kCycW; ++q) same = same && (old.v[q] == cur.v[q]);
+          if (same) {
+            int r = (velIters - 1 - it) % p;
+            if (r != 0) cycUnpack(rGet(cyc, (it - p + r) & (kCycP - 1)));
+            found = true;
+          }
+        }
+        if (found) break;
+        rSet(cyc, it & (kCycP - 1), cur);
+      }
+    }
+    return done;
+  }
+
+  // position iterations; returns positionSolved
+  __device__ __forceinline__ bool positionIterations(int posIters, int* itersDone) {
+    bool positionSolved = false;
+    int n = 0;
+    for (int it = 0; it < posIters; ++it) {
+      float minSeparation = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NCR; ++k)
+        if (k < nc) minSeparation = positionContact(ct[k], minSeparation);
+      ++n;
+      bool contactsOkay = minSeparation >= -3.0f * kLinearSlop;
+      bool jointsOkay = true;
+      if constexpr (NJR > 0) {
+#pragma unroll
+        for (int k = 0; k < NJR; ++k)
+          if (k < nj) {
+            bool ok = positionJoint(jt[k]);
+            jointsOkay = jointsOkay && ok;
+          }
+      }
+      if (contactsOkay && jointsOkay) {
+        positionSolved = true;
+        break;
+      }
+    }
+    *itersDone = n;
+    return positionSolved;
+  }
+};
+
+}  // namespace blcd

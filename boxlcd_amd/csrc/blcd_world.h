@@ -18,6 +18,7 @@
 #include <utility>
 #include "blcd_toi.h"
 #include "blcd_toi_wall.h"
+#include "blcd_island_reg.h"
 
 namespace blcd {
 
@@ -1266,7 +1267,201 @@ struct Env {
     }
   }
 
+  // ------------------------------------------------------------------------------------------------
+  // register-resident island solve (blcd_island_reg.h) for multi-body scenes: islands with <= kRegC contacts
+  // ------------------------------------------------------------------------------------------------
+  static constexpr bool kUseReg = (NB > 1) && (NB <= 8) && (NJ <= 4);
+  static constexpr int kRegC = 4;
+  __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
+    const int nb = S->nb;
+    Vec2 gravity = S->gravity;
+    RegIsland<NB, NJ, kRegC> R;
+    R.nc = nic;
+    R.nj = nij;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      bool in = i < nb && ((ibmask >> i) & 1);
+      Vec2 v_ = v[i];
+      float w_ = w[i];
+      if (in) {
+        c0[i] = c[i];
+        a0[i] = a[i];
+        v_ += h * (1.0f * gravity + invMass[i] * V2(0.0f, 0.0f));
+        w_ += h * invI[i] * 0.0f;
+        v_ *= 1.0f / (1.0f + h * S->bodies[i].linearDamping);
+        w_ *= 1.0f / (1.0f + h * S->bodies[i].angularDamping);
+      }
+      R.pos[i].c = c[i];
+      R.pos[i].a = a[i];
+      R.vel[i].v = v_;
+      R.vel[i].w = w_;
+      R.mass[i].invMass = invMass[i];
+      R.mass[i].invI = invI[i];
+      R.mass[i].lc = lc[i];
+    }
+    // contacts in island order: b2ContactSolver ctor + InitializeVelocityConstraints
+    Manifold mans[kRegC];
+#pragma unroll
+    for (int k = 0; k < kRegC; ++k) {
+      if (k < nic) {
+        int s = ic.get(k);
+        RContact& c_ = R.ct[k];
+        const Manifold m = selGet(man, s);
+        mans[k] = m;
+        slotAB(s, &c_.pA, &c_.pB);
+        c_.friction = S->pairs[s].friction;
+        c_.restitution = S->pairs[s].restitution;
+        c_.pointCount = m.pointCount;
+        c_.K.ex = c_.K.ey = V2(0.0f, 0.0f);
+        c_.normalMass.ex = c_.normalMass.ey = V2(0.0f, 0.0f);
+        c_.mtype = m.type;
+        c_.mcount = m.pointCount;
+        c_.localNormal = m.localNormal;
+        c_.localPoint = m.localPoint;
+        c_.lp0 = m.points[0].localPoint;
+        c_.lp1 = m.points[1].localPoint;
+        c_.radiusA = shapeOf(c_.pA)->radius;
+        c_.radiusB = shapeOf(c_.pB)->radius;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          RPoint& p = c_.points[j];
+          p.normalImpulse = dtRatio * m.points[j].normalImpulse;
+          p.tangentImpulse = dtRatio * m.points[j].tangentImpulse;
+          p.rA = V2(0.0f, 0.0f);
+          p.rB = V2(0.0f, 0.0f);
+          p.normalMass = 0.0f;
+          p.tangentMass = 0.0f;
+          p.velocityBias = 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRegC; ++k)
+      if (k < nic) R.initContact(R.ct[k], mans[k]);
+#pragma unroll
+    for (int k = 0; k < kRegC; ++k)
+      if (k < nic) R.warmStartContact(R.ct[k]);
+    if constexpr (NJ > 0) {
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) {
+        if (k < nij) {
+          int j = ij[k];
+          const DevJoint& J = S->joints[j];
+          RJoint& r = R.jt[k];
+          r.A = J.bodyA;
+          r.B = J.bodyB;
+          r.anchorA = J.anchorA;
+          r.anchorB = J.anchorB;
+          r.enableLimit = J.enableLimit;
+          r.lower = J.lower;
+          r.upper = J.upper;
+          r.maxMotorTorque = J.maxMotorTorque;
+          r.ref = jref[j];
+          r.speed = jspeed[j];
+          r.imp = jimp[j];
+          r.motor = jmotor[j];
+          r.limit = jlimit[j];
+          R.initJoint(r, dtRatio);
+        }
+      }
+    }
+    int sweeps = R.velocitySweeps(S->velIters, h);
+    prof[6] += sweeps;
+    // b2ContactSolver::StoreImpulses
+#pragma unroll
+    for (int k = 0; k < kRegC; ++k) {
+      if (k < nic) {
+        int s = ic.get(k);
+        Manifold m = mans[k];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (j < R.ct[k].pointCount) {
+            m.points[j].normalImpulse = R.ct[k].points[j].normalImpulse;
+            m.points[j].tangentImpulse = R.ct[k].points[j].tangentImpulse;
+          }
+        selSet(man, s, m);
+      }
+    }
+    // integrate positions
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (i < nb && ((ibmask >> i) & 1)) {
+        Vec2 c_ = R.pos[i].c;
+        float a_ = R.pos[i].a;
+        Vec2 v_ = R.vel[i].v;
+        float w_ = R.vel[i].w;
+        Vec2 translation = h * v_;
+        if (Dot(translation, translation) > kMaxTranslationSquared) {
+          float ratio = kMaxTranslation / Length(translation);
+          v_ *= ratio;
+        }
+        float rotation = h * w_;
+        if (rotation * rotation > kMaxRotationSquared) {
+          float ratio = kMaxRotation / Abs(rotation);
+          w_ *= ratio;
+        }
+        c_ += h * v_;
+        a_ += h * w_;
+        R.pos[i].c = c_;
+        R.pos[i].a = a_;
+        R.vel[i].v = v_;
+        R.vel[i].w = w_;
+      }
+    }
+    int pit = 0;
+    bool positionSolved = R.positionIterations(S->posIters, &pit);
+    prof[7] += pit;
+    // copy back
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (i < nb && ((ibmask >> i) & 1)) {
+        c[i] = R.pos[i].c;
+        a[i] = R.pos[i].a;
+        v[i] = R.vel[i].v;
+        w[i] = R.vel[i].w;
+        syncTransform(i);
+      }
+    }
+    if constexpr (NJ > 0) {
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) {
+        if (k < nij) {
+          int j = ij[k];
+          jimp[j] = R.jt[k].imp;
+          jmotor[j] = R.jt[k].motor;
+          jlimit[j] = R.jt[k].limit;
+        }
+      }
+    }
+    float minSleepTime = kMaxFloat;
+    const float linTolSqr = kLinearSleepTolerance * kLinearSleepTolerance;
+    const float angTolSqr = kAngularSleepTolerance * kAngularSleepTolerance;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (i < nb && ((ibmask >> i) & 1)) {
+        if (w[i] * w[i] > angTolSqr || Dot(v[i], v[i]) > linTolSqr) {
+          sleepTime[i] = 0.0f;
+          minSleepTime = 0.0f;
+        } else {
+          sleepTime[i] += h;
+          minSleepTime = Min(minSleepTime, sleepTime[i]);
+        }
+      }
+    }
+    if (minSleepTime >= kTimeToSleep && positionSolved) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (i < nb && ((ibmask >> i) & 1)) sleepBody(i);
+    }
+  }
+
   __device__ __forceinline__ void islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
+    if constexpr (kUseReg) {
+      if (nic <= kRegC) {
+        islandSolveReg(ibmask, nic, nij, h, dtRatio);
+        return;
+      }
+    }
     const int nb = S->nb;
     Vec2 gravity = S->gravity;
     for (int i = 0; i < NB; ++i) {
