@@ -62,14 +62,16 @@ def test_render_poses_equals_oracle_and_pillow(name, variant):
 
 
 def test_gif_sequences_on_device():
-  """The reference's published Dropbox/Bounce LCD sequences, reproduced by the HIP path itself."""
+  """The reference's published LCD sequences (ball, box, ball-ball, box-ball, box-box), reproduced by the HIP path itself."""
+  from test_oracle_physics import BOX_AND_BALL_START, CUBES_START
   gifs = np.load('tests/golden/gif_lcd_frames.npz')
-  for name, key, pose, T in [('Dropbox', 'Dropbox', [[1.66, 4.015, 1.315]], 26), ('Bounce', 'Bounce', [[1.55, 4.17, 0.0]], 50),
+  for name, key, pose, sel, T in [('Object2', 'Object2', BOX_AND_BALL_START, [1, 0], 50), ('Object2', 'Object2_cubes', CUBES_START, [1, 1], 50)] + [
+      (n_, k_, p_, None, t_) for n_, k_, p_, t_ in [('Dropbox', 'Dropbox', [[1.66, 4.015, 1.315]], 26), ('Bounce', 'Bounce', [[1.55, 4.17, 0.0]], 50),
                              ('Bounce2', 'Bounce2', [[1.60323, 4.17499, 0.0], [2.47265, 3.01481, 0.0]], 50),
-                             ('Object2', 'Object2_circles', [[3.7294, 2.56002, 0.0], [3.58992, 0.70644, 0.0]], 50)]:
+                             ('Object2', 'Object2_circles', [[3.7294, 2.56002, 0.0], [3.58992, 0.70644, 0.0]], 50)]]:
     env = getattr(B.envs, name)()
     h = Handle(env.scene.desc, 1, 0)
-    h.reset(None, np.array([pose], np.float32), None)
+    h.reset(None, np.array([pose], np.float32), None if sel is None else np.array([sel], np.int32))
     lcd = np.zeros((T, 1, 16, 16), np.uint8)
     h.rollout(None, T, lcd_out=lcd)
     exp = np.unpackbits(gifs[key], axis=-1)[:, :, :16]
