@@ -4,8 +4,10 @@
 // draw.ellipse / draw.polygon(fill=0) per dynamic body + FLIP_TOP_BOTTOM.  The scan-conversion rules are Pillow's
 // (`ImagingDrawPolygon` / `polygon_generic` / `hline8`, `ImagingDrawEllipse`) as characterised in SURVEY.md App. C:
 // int truncation of the float64 pixel coordinates, float32 edge interpolation, half-open RU/RD rounding, lower-end
-// duplication; variant 1 adds Pillow >= 12's sub-pixel corner joining, variant 0 is the legacy rule the reference's
-// published frames show.  Drawing order is irrelevant in mode '1' (every body clears bits).
+// duplication; variant 0 is the rule of the Pillow the reference pins (9.0.1: horizontal-edge spans + span merging),
+// variant 1 adds Pillow >= 12's sub-pixel corner joining, variant 2 is the Pillow 8.2-8.4 rule the reference's published
+// demo GIFs were recorded with (horizontal edges skipped, plain pairing, crossed span ends swapped): they differ only on
+// thin links that truncate to degenerate polygons.  Drawing order is irrelevant in mode '1' (every body clears bits).
 #pragma once
 #include "blcd_collide.h"
 #include "blcd_ellipse_lut.h"
@@ -68,7 +70,7 @@ struct Raster {
       if (ymin > e[i].ymin) ymin = e[i].ymin;
       if (ymax < e[i].ymax) ymax = e[i].ymax;
       if (e[i].ymin == e[i].ymax) {
-        hline(e[i].xmin, e[i].ymin, e[i].xmax);
+        if (variant != 2) hline(e[i].xmin, e[i].ymin, e[i].xmax);
         continue;
       }
       table[edge_count++] = i;
@@ -113,6 +115,13 @@ struct Raster {
           --t;
         }
         xx[t + 1] = key;
+      }
+      if (variant == 2) {
+        for (int i = 1; i < j; i += 2) {
+          int a = RoundUp(xx[i - 1]), b = RoundDown(xx[i]);
+          hline(a < b ? a : b, y, a < b ? b : a);
+        }
+        continue;
       }
       int x_pos = 0;
       for (int i = 1; i < j; i += 2) {

@@ -77,7 +77,8 @@ typedef struct blcd_obs_def {
 typedef struct blcd_scene_desc {
   int32_t n_bodies, n_joints, n_shapes, n_obs, n_act;
   int32_t lcd_w, lcd_h;   /* int(lcd_base*wh_ratio), lcd_base (world_env.py:467-469) */
-  int32_t raster_variant; /* 0 legacy Pillow scan rule, 1 Pillow >= 12 corner joining */
+  int32_t raster_variant; /* Pillow polygon scan rule: 0 = 9.0.x (the reference's pin), 1 = >= 12 (corner joining),
+                             2 = 8.2-8.4 (what the reference's demo GIFs were recorded with); SURVEY.md App. C.4b */
   float world_w, world_h; /* WIDTH = int(wh_ratio*base_dim), HEIGHT (world_env.py:144-150) */
   float gravity[2];
   float dt;               /* float32(1/(fps*3)) (world_env.py:448) */

@@ -53,7 +53,7 @@ typedef struct b2o_obs_def {
 
 typedef struct b2o_scene_desc {
   int32_t n_bodies, n_joints, n_shapes, n_obs, n_act;
-  int32_t lcd_w, lcd_h, raster_variant; /* 0 legacy, 1 modern */
+  int32_t lcd_w, lcd_h, raster_variant; /* 0 legacy, 1 modern, 2 recording era */
   float world_w, world_h;               /* WIDTH = int(wh_ratio*base_dim), HEIGHT = base_dim */
   float gravity[2];
   float dt;                             /* float32(1/(fps*3)) */

@@ -5,7 +5,8 @@
 // FLIP_TOP_BOTTOM).  Pillow (`Pillow==9.0.1`, requirements.txt:19) is un-vendored; the scan-conversion rules are
 // the behavioural spec of SURVEY.md App. C (probed against Pillow 12.2.0):
 //   variant 1 "modern"  = Pillow 12.2.0 (with sub-pixel corner joining)      -> pinned by tests/golden/pillow_*.npz
-//   variant 0 "legacy"  = the same scan rule without corner joining (what the reference's published GIF frames show)
+//   variant 0 "legacy"  = the same scan rule without corner joining (the Pillow 9.0.x the reference pins)
+//   variant 2 "recording era" = Pillow 8.2-8.4, what the reference's published GIFs were rendered with (see below)
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -47,6 +48,17 @@ static inline void add_edge(Edge* e, int x0, int y0, int x1, int y1) {
 }
 static inline float edge_x(const Edge* e, int y) { return (y - e->y0) * e->dx + e->x0; }
 
+// Variant 2, "recording era": the polygon fill of the Pillow 8.2-8.4 releases that were current when the reference's demo
+// GIFs were recorded (2021; the repository pinned Pillow 9.0.1 later).  Relative to variant 0: horizontal edges are
+// skipped instead of drawn, crossings are paired without span merging, and a span whose rounded ends cross (x0 > x1,
+// two coincident crossings at k+0.5) is drawn with its ends swapped, as that era's hline did.
+// Only used by tests/test_oracle_physics.py to compare against the robot GIFs (thin links truncate to degenerate
+// polygons there, which later releases draw differently); the product implements variants 0 and 1 only.
+static inline void hline_swapping(Canvas& im, int x0, int y0, int x1) {
+  if (x0 > x1) std::swap(x0, x1);
+  hline(im, x0, y0, x1);
+}
+
 // ImagingDrawPolygon(fill) on integer vertices
 static inline void draw_polygon(Canvas& im, const int* xy, int count, int variant) {
   const int MAXE = 40;
@@ -63,7 +75,7 @@ static inline void draw_polygon(Canvas& im, const int* xy, int count, int varian
     if (ymin > e[i].ymin) ymin = e[i].ymin;
     if (ymax < e[i].ymax) ymax = e[i].ymax;
     if (e[i].ymin == e[i].ymax) {
-      hline(im, e[i].xmin, e[i].ymin, e[i].xmax);
+      if (variant != 2) hline(im, e[i].xmin, e[i].ymin, e[i].xmax);
       continue;
     }
     table[edge_count++] = &e[i];
@@ -101,6 +113,10 @@ static inline void draw_polygon(Canvas& im, const int* xy, int count, int varian
       }
     }
     std::sort(xx, xx + j);
+    if (variant == 2) {
+      for (int i = 1; i < j; i += 2) hline_swapping(im, RoundUp(xx[i - 1]), y, RoundDown(xx[i]));
+      continue;
+    }
     int x_pos = 0;
     for (int i = 1; i < j; i += 2) {
       int x_end = RoundDown(xx[i]);

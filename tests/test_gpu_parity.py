@@ -47,7 +47,8 @@ def test_mass_data_equals_oracle():
       assert (out == pyb2o.mass_data(d, sh, 0.37)).all(), (name, sh)
 
 
-@pytest.mark.parametrize('name,variant', [('Urchin', 0), ('Urchin', 1), ('LuxoBall', 1), ('Crab', 1), ('Object2', 0)])
+@pytest.mark.parametrize('name,variant', [('Urchin', 0), ('Urchin', 1), ('Urchin', 2), ('LuxoBall', 1), ('LuxoBall', 2), ('Crab', 1), ('Crab', 2),
+                                          ('Object2', 0)])
 def test_render_poses_equals_oracle_and_pillow(name, variant):
   env = B.BatchedWorldEnv(name, 1, raster_variant=variant)
   g = np.load('tests/golden/pillow_render.npz')
@@ -76,6 +77,28 @@ def test_gif_sequences_on_device():
     h.rollout(None, T, lcd_out=lcd)
     exp = np.unpackbits(gifs[key], axis=-1)[:, :, :16]
     assert (lcd[:, 0] == exp).all(), key
+    h.close()
+
+
+def test_robot_gif_sequences_on_device():
+  """Robot recordings (revolute joints, motors, limits; known action tape, see tests/test_oracle_physics.py) replayed by the
+  HIP path with the recording-era raster rule: Urchin 100/100 and UrchinBall 150/150 frames identical, Luxo all but the
+  documented 6 px."""
+  import json
+  gifs = np.load('tests/golden/gif_lcd_frames.npz')
+  starts = json.load(open('tests/golden/gif_robot_starts.json'))
+  for name, budget in [('Urchin', 0), ('UrchinBall', 0), ('Luxo', 6), ('LuxoBall', 7)]:
+    env = getattr(B.envs, name)(raster_variant=2)
+    W = env.scene.desc.lcd_w
+    exp = np.unpackbits(gifs[name], axis=-1)[:, :, :W]
+    T = len(exp)
+    rs = np.random.RandomState(4)
+    acts = np.stack([rs.uniform(-1, 1, env.act_size) for _ in range(T)]).astype(np.float32)[:, None, :]
+    h = Handle(env.scene.desc, 1, 0)
+    h.reset(None, np.array([starts[name]], np.float32), None)
+    lcd = np.zeros((T, 1, 16, W), np.uint8)
+    h.rollout(acts, T, lcd_out=lcd)
+    assert int((lcd[:, 0] != exp).sum()) <= budget, name
     h.close()
 
 

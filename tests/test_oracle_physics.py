@@ -89,6 +89,74 @@ def test_cubes_gif_exact(oracle):
   assert sum(bad) == 0 and body_body >= 2, bad
 
 
+# ---- robot GIFs: revolute joints, motors, limits ---------------------------------------------------------------------
+# The reference's demo recorder (research/scripts/evaluations/demo_imgs.py:60-72) seeds the env with 7 and feeds
+# np.random.RandomState(4).uniform(-1, 1, act_dim) every step.  With that action tape and the seed-7 reset sample (refined
+# by <= 1e-3 with tools/fit_gif_gpu.py; stored in tests/golden/gif_robot_starts.json) the oracle reproduces the robot
+# recordings.  They were rendered with the Pillow of 2021 (raster variant 2: see oracle/b2o_raster.h), which only
+# matters where a thin link truncates to a degenerate polygon.
+def _robot_gif(oracle, name):
+  import json
+  start = json.load(open('tests/golden/gif_robot_starts.json'))[name]
+  env = getattr(B.envs, name)(raster_variant=2)
+  gif = _gif(name, env.scene.desc.lcd_w)
+  o = oracle.OracleEnv(env.scene.desc)
+  o.reset(np.array(start, np.float32), [0] * len(start))
+  rs = np.random.RandomState(4)
+  bad, limit_frames = [], 0
+  for t in range(len(gif)):
+    o.step(rs.uniform(-1, 1, env.act_size).astype(np.float32))
+    bad.append(int((o.render() != gif[t]).sum()))
+    limit_frames += int((o.dump()[1][:, 4] != 0).any())
+  return bad, limit_frames
+
+
+def test_urchin_gif_exact(oracle):
+  """assets/envs/Urchin.gif: 3 motorised, limited revolute joints under random torques, 4-body island on the floor -
+  100/100 frames identical (b2RevoluteJoint motor + limit + point constraint, joint/contact ordering, island solve)."""
+  bad, limit_frames = _robot_gif(oracle, 'Urchin')
+  assert sum(bad) == 0 and limit_frames > 10, (bad, limit_frames)
+
+
+def test_urchin_ball_gif_exact(oracle):
+  """assets/envs/UrchinBall.gif: the same robot kicking a ball - 150/150 frames identical."""
+  bad, _ = _robot_gif(oracle, 'UrchinBall')
+  assert sum(bad) == 0, bad
+
+
+def test_luxo_gifs_near_exact(oracle):
+  """Luxo.gif (100 frames) and LuxoBall.gif (150): identical except the frame where the lamp's flat foot is pressed
+  against the left wall (6 px: the recording draws the foot's degenerate polygon there, our variant 2 does not) and one
+  more pixel in LuxoBall.  The dynamics (limits at +-0.5..., 5-vertex lamp head) are reproduced to the last frame."""
+  bad, _ = _robot_gif(oracle, 'Luxo')
+  assert sum(bad) == 6 and bad[37] == 6, bad
+  bad, limit_frames = _robot_gif(oracle, 'LuxoBall')
+  assert sum(bad) <= 7 and sum(b == 0 for b in bad) >= 148 and limit_frames > 10, bad
+
+
+def test_urchin_cube_gif_prefix(oracle):
+  """UrchinCube.gif: robot + box; identical for the first 99 frames and 121 of 150 overall (then the fit's residual start
+  error is amplified by the box's tumbling - chaotic, not a modelling difference: the other recordings stay exact)."""
+  bad, _ = _robot_gif(oracle, 'UrchinCube')
+  assert sum(bad[:99]) == 0 and sum(b == 0 for b in bad) >= 120, bad
+
+
+def test_seed7_reset_sample_matches_recordings():
+  """The recordings' fitted start poses coincide with OUR restatement of gym-0.17 seeding + the reference's sampling order
+  (world_env.py:197-304) for seed 7 - a pin of np_random()/_sample_poses() (no GPU, no oracle needed)."""
+  import json
+  starts = json.load(open('tests/golden/gif_robot_starts.json'))
+  starts['Bounce2'] = [[1.60323, 4.17499, 0.0], [2.47265, 3.01481, 0.0]]
+  for name, fit in starts.items():
+    env = getattr(B.envs, name)()
+    env.seed(7)
+    poses, _ = env._sample_poses(lambda lo, hi: np.array([env.np_random.uniform(lo, hi)]), 1)
+    d = np.abs(poses[0, :, :2] - np.array(fit)[:, :2]).max()
+    assert d < 6e-3, (name, d)
+    if name != 'Bounce2':
+      assert np.abs(poses[0, :, 2] - np.array(fit)[:, 2]).max() < 1e-2, name
+
+
 def test_free_fall_increments(oracle):
   """Semi-implicit Euler, 3 sub-steps of 1/30 s: env-step k moves by -(g/900)(9k-3)."""
   _, o = _env(oracle, 'Dropbox', [[2.5, 3.6, 0.3]])

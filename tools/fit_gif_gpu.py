@@ -56,10 +56,78 @@ def run(key, sel, centres, half, N=400000, gens=8, out=None):
                'prefix': int(fb[order[0]]), 'topranked_mismatch': int(tot_c[order[0]])}, open(out, 'w'))
   h.close()
 
+def run_robot(name, N=200000, gens=12, half=0.004, wide_from=None):
+  """Robot GIFs: actions are known (demo_imgs.py:60-72: env.seed(7), RandomState(4).uniform(-1,1,A) per step); the start is
+  the seed-7 sample up to small offsets.  Search in the space of the reset's uniform draws around the seed-7 draws."""
+  env1 = getattr(B.envs, name)()
+  W = env1.scene.desc.lcd_w
+  gif = np.unpackbits(np.load('tests/golden/gif_lcd_frames.npz')[name], axis=-1)[:, :, :W]
+  T = len(gif)
+  env1.seed(7)
+  log = []
+  def rec(lo, hi):
+    v = env1.np_random.uniform(lo, hi); log.append((lo, hi, v)); return np.array([v])
+  env1._sample_poses(rec, 1)
+  lo = np.array([l[0] for l in log]); hi = np.array([l[1] for l in log]); u0 = np.array([l[2] for l in log])
+  free = hi > lo
+  print(name, 'draws', [(round(a, 4), round(b, 4), round(c, 6)) for a, b, c in log], flush=True)
+  A = env1.act_size
+  rs = np.random.RandomState(4)
+  acts = np.stack([rs.uniform(-1, 1, A) for _ in range(T)]).astype(np.float32)
+  h = Handle(env1.scene.desc, N, 0)
+  acts_d = torch.from_numpy(acts)[:, None, :].expand(T, N, A).contiguous().cuda()
+  g = torch.as_tensor(gif).cuda()
+  lcd = torch.empty((T, N, 16, W), dtype=torch.uint8, device='cuda')
+  rng = np.random.RandomState(0)
+  k = len(u0)
+  U = u0 + rng.uniform(-1, 1, (N, k)) * half * free
+  if wide_from is not None:      # draws >= wide_from (the object's) start uniform over their whole range
+    U[:, wide_from:] = lo[wide_from:] + rng.uniform(0, 1, (N, k - wide_from)) * (hi - lo)[wide_from:]
+  U[0] = u0
+  best = (10**9, None, None)
+  for gen in range(gens):
+    U = np.clip(U, lo, hi)
+    col = [0]
+    def take(l, h_):
+      c = col[0]; col[0] += 1; return U[:, c]
+    poses, sel = env1._sample_poses(take, N, randint=lambda m, n: np.zeros(n, np.int64))
+    h.reset(None, poses, sel)
+    h.rollout(acts_d, T, lcd, None)
+    torch.cuda.synchronize()
+    mism = torch.stack([(lcd[t] != g[t][None]).sum(dim=(1, 2)) for t in range(T)])     # [T, N]
+    tot = mism.sum(0)
+    first_bad = torch.where(mism > 0, torch.arange(T, device='cuda')[:, None], T).min(0).values
+    if os.environ.get('FIT_RANK', 'prefix') == 'exact':   # number of exact frames: tolerant of isolated raster anomalies
+      first_bad = (mism == 0).sum(0)
+    order = torch.argsort(tot.to(torch.int64) - first_bad.to(torch.int64) * 100000)[:2000].cpu().numpy()
+    tot_c = tot.cpu().numpy(); fb = first_bad.cpu().numpy()
+    ib = int(np.argmin(tot_c))
+    if tot_c[ib] < best[0]:
+      best = (int(tot_c[ib]), U[ib].tolist(), poses[ib].astype(float).tolist())
+    print(f'gen {gen}: top-ranked mismatch {int(tot_c[order[0]])} prefix {int(fb[order[0]])}; min mismatch {int(tot_c.min())}; #exact {int((tot_c == 0).sum())}', flush=True)
+    if best[0] == 0:
+      break
+    elite = U[order[:500]]
+    scales = half * np.array([1.0, 0.3, 0.1, 0.03, 0.01, 0.003, 0.001, 0.0003]) * (10.0 if wide_from is not None and gen < 4 else 1.0)
+    reps = N // (len(elite) * len(scales))
+    U = np.concatenate([np.repeat(elite, reps, 0) + rng.normal(0, 1, (len(elite) * reps, k)) * s * free for s in scales])
+    U = np.concatenate([U, elite[rng.randint(0, len(elite), N - len(U))]]) if len(U) < N else U[:N]
+  print('RESULT', name, best[0], 'draws', best[1], 'poses', best[2], flush=True)
+  json.dump({'name': name, 'mismatch': best[0], 'draws': best[1], 'poses': best[2], 'seed7_draws': u0.tolist()},
+            open(f'gpurun_out/fit_robot_{name}.json', 'w'))
+  h.close()
+  del lcd, acts_d
+  torch.cuda.empty_cache()
+
+
 if __name__ == '__main__':
   which = sys.argv[1]
   hp = np.pi / 2
-  if which == 'cubes2':   # second stage around the best candidate of the first
+  if which == 'robots':
+    for nm in sys.argv[2:]:
+      nm, _, wf = nm.partition(':')
+      run_robot(nm, wide_from=int(wf) if wf else None, N=int(os.environ.get('FIT_N', 200000)), gens=int(os.environ.get('FIT_GENS', 12)))
+  elif which == 'cubes2':   # second stage around the best candidate of the first
     cs = [[0.8719531, 2.3441846, 0.5894453, 1.8819505, 4.429913, -0.221729]]
     run('Object2_cubes', [1, 1], cs, [0.003] * 6, N=int(os.environ.get('FIT_N', 1000000)),
         gens=int(os.environ.get('FIT_GENS', 20)), out='gpurun_out/fit_cubes2.json')
