@@ -106,6 +106,7 @@ struct RegIsland {
   RJoint jt[NJR > 0 ? NJR : 1];
   RContact ct[NCR];
   int nj, nc;
+  uint32_t deadQ;  // Env::deadQ
 
   // ---- body accessors by proxy id ----
   __device__ __forceinline__ BodyVel V(int p) const {
@@ -147,8 +148,8 @@ struct RegIsland {
     Vec2 cA = pa_.c, cB = pb_.c, vA = va_.v, vB = vb_.v;
     float aA = pa_.a, aB = pb_.a, wA = va_.w, wB = vb_.w;
     Transform xfA, xfB;
-    xfA.q.Set(aA);
-    xfB.q.Set(aB);
+    xfA.q = rotDead(deadQ, pA, aA);
+    xfB.q = rotDead(deadQ, pB, aB);
     xfA.p = cA - Mul(xfA.q, mAs.lc);
     xfB.p = cB - Mul(xfB.q, mBs.lc);
     WorldManifold worldManifold;
@@ -331,8 +332,8 @@ struct RegIsland {
     for (int j = 0; j < 2; ++j) {
       if (j >= c_.mcount) break;
       Transform xfA, xfB;
-      xfA.q.Set(aA);
-      xfB.q.Set(aB);
+      xfA.q = rotDead(deadQ, c_.pA, aA);
+      xfB.q = rotDead(deadQ, c_.pB, aB);
       xfA.p = cA - Mul(xfA.q, localCenterA);
       xfB.p = cB - Mul(xfB.q, localCenterB);
       Vec2 normal, point;

@@ -289,6 +289,18 @@ struct Mat33 {
   }
 };
 
+// see Env::rotFor
+BLCD_HD static inline Rot rotDead(uint32_t deadMask, int p, float angle) {
+  Rot r;
+  if ((deadMask >> p) & 1u) {
+    r.s = 0.0f;
+    r.c = 1.0f;
+  } else {
+    r.Set(angle);
+  }
+  return r;
+}
+
 struct Sweep {
   Vec2 localCenter, c0, c;
   float a0, a, alpha0;

@@ -217,6 +217,7 @@ struct TOIWall {
   // ---- exact memo of sweepB.GetTransform(t): the TOI iteration asks for the same t repeatedly (t1 in the outer loop, the
   // separation function's Initialize/Evaluate; tMax in every FindMinSeparation; the root it just found).  The sweep is
   // fixed during one TOI query, so GetTransform is a pure function of t and replaying a stored result is bit-identical.
+  bool qDead;               // see xfAt
   float mkA, mkB, mkC;      // keys (NaN = empty)
   Transform mxA, mxB, mxC;  // A: current t1, B: tMax, C: most recent other t
   __device__ __forceinline__ void memoReset() {
@@ -227,7 +228,16 @@ struct TOIWall {
     if (t == mkB) return mxB;
     if (t == mkC) return mxC;
     Transform xf;
-    sweepB.GetTransform(&xf, t);
+    if (MAXV == 1 && qDead) {
+      // circle whose centre is the body origin (and the centre of mass): every use of q below multiplies the zero vector
+      // (vertex (0,0), localCenter (0,0); the support of a 1-vertex proxy is always 0), so sincosf is skipped.  Values are
+      // unchanged; only the sign of an exact zero could differ.
+      xf.p = (1.0f - t) * sweepB.c0 + t * sweepB.c;
+      xf.q.s = 0.0f;
+      xf.q.c = 1.0f;
+    } else {
+      sweepB.GetTransform(&xf, t);
+    }
     mkC = t;
     mxC = xf;
     return xf;
@@ -329,6 +339,7 @@ struct TOIWall {
     output->t = tMax;
     sweepB = sweepB_in;
     sweepB.Normalize();
+    qDead = MAXV == 1 && B.vx[0] == 0.0f && B.vy[0] == 0.0f && sweepB.localCenter.x == 0.0f && sweepB.localCenter.y == 0.0f;
     float totalRadius = A.radius + B.radius;
     float target = Max(kLinearSlop, totalRadius - 3.0f * kLinearSlop);
     float tolerance = 0.25f * kLinearSlop;

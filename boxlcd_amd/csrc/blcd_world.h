@@ -230,6 +230,7 @@ struct Env {
     S = scene;
     const int nb = S->nb, nj = S->nj, np = S->np;
     awakeMask = 0;
+    deadQ = 15u;
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
       const float* p = st + (size_t)(i * kBodyFields) * N + e;
@@ -251,6 +252,8 @@ struct Env {
       invMass[i] = var.invMass;
       invI[i] = var.invI;
       lc[i] = var.localCenter;
+      const Shape& shp = S->shapes[var.shape];
+      if (shp.type == kCircle && shp.v[0].x == 0.0f && shp.v[0].y == 0.0f && lc[i].x == 0.0f && lc[i].y == 0.0f) deadQ |= 16u << i;
     }
     const float* pp = st + (size_t)(nb * kBodyFields) * N + e;
 #pragma unroll kUS
@@ -390,6 +393,12 @@ struct Env {
     }
     return t;
   }
+  // Rotation used by the CONTACT code for proxy p at angle `angle`.  Walls sit at angle 0 (sincosf(0) == (0, 1) exactly).
+  // For a circle centred on its body origin, with the centre of mass there too, every contact-side use of q multiplies the
+  // zero vector (xf.p = c - q*localCenter; manifold local points are the circle centre), so sincosf is skipped: values are
+  // unchanged, only the sign of an exact zero could differ.  The body's stored transform (synchronizeTransform) is real.
+  uint32_t deadQ;
+  __device__ __forceinline__ Rot rotFor(int p, float angle) const { return rotDead(deadQ, p, angle); }
   __device__ __forceinline__ const Shape* shapeOf(int p) const {
     if (p < 4) return &S->wallShape[p];
     int i = bi(p);
@@ -466,7 +475,7 @@ struct Env {
   }
   __device__ __forceinline__ void synchronizeFixtures(int i) {  // b2Body::SynchronizeFixtures
     Transform xf1;
-    xf1.q.Set(a0[i]);
+    xf1.q = rotFor(4 + i, a0[i]);
     xf1.p = c0[i] - Mul(xf1.q, lc[i]);
     synchronizeProxy(i, xf1, xfOf(4 + i));
   }
@@ -652,8 +661,8 @@ struct Env {
       Vec2 vB = Pv(pB);
       float wB = Pw(pB);
       Transform xfA, xfB;
-      xfA.q.Set(aA);
-      xfB.q.Set(aB);
+      xfA.q = rotFor(pA, aA);
+      xfB.q = rotFor(pB, aB);
       xfA.p = cA - Mul(xfA.q, localCenterA);
       xfB.p = cB - Mul(xfB.q, localCenterB);
       WorldManifold worldManifold;
@@ -883,8 +892,8 @@ struct Env {
       for (int j = 0; j < 2; ++j) {
         if (j >= pointCount) break;
         Transform xfA, xfB;
-        xfA.q.Set(aA);
-        xfB.q.Set(aB);
+        xfA.q = rotFor(pA, aA);
+        xfB.q = rotFor(pB, aB);
         xfA.p = cA - Mul(xfA.q, localCenterA);
         xfB.p = cB - Mul(xfB.q, localCenterB);
         Vec2 normal, point;
@@ -1278,6 +1287,7 @@ struct Env {
     RegIsland<NB, NJ, kRegC> R;
     R.nc = nic;
     R.nj = nij;
+    R.deadQ = deadQ;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       bool in = i < nb && ((ibmask >> i) & 1);
