@@ -11,8 +11,8 @@
 #include <string>
 #include <vector>
 #include "../../include/boxlcd.h"
-#include "blcd_raster.h"
-#include "blcd_world.h"
+#include "blcd_emit.h"
+#include "blcd_cfg_launch.h"
 
 using namespace blcd;
 
@@ -33,104 +33,6 @@ static int fail(int code, const std::string& msg) {
 // ---------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kBlock = 64;  // one wave per workgroup: N/64 workgroups spread over 256 CUs
-
-
-// observation (boxLCD/world_env.py:387-429, float64 glue) + LCD raster (:460-512) of one environment; `body(i, &p, &a, &sel)`
-// yields transform position, body angle and shape choice of body i.  Shared by obs_kernel and the fused rollout path.
-template <int H, typename RowT, typename ObsT, typename BodyFn>
-__device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn body, ObsT* __restrict__ obsRow,
-                                         uint8_t* __restrict__ lcdRow) {
-  bool ok = true;
-  if (obsRow) {
-    for (int i = 0; i < S->nobs; ++i) {
-      const DevObs od = S->obs[i];
-      Vec2 p;
-      float a;
-      int sel;
-      body(od.body, &p, &a, &sel);
-      double val;
-      if (od.kind == 0) val = (double)p.x;
-      else if (od.kind == 1) val = (double)p.y;
-      else {
-        if (od.kind >= 4) {  // transform.angle = atan2f(q.s, q.c)
-          Rot q;
-          q.Set(a);
-          a = atan2f(q.s, q.c);
-        }
-        val = (od.kind == 2 || od.kind == 4) ? cos((double)a) : sin((double)a);
-      }
-      double lo = (double)od.lo, hi = (double)od.hi;
-      obsRow[i] = (ObsT)(((val - lo) / (hi - lo) * 2.0) + -1.0);
-    }
-  }
-  if (lcdRow) {
-    Raster<H, RowT> r;
-    r.clear(S->lcdW, S->rasterVariant);
-    for (int i = 0; i < S->nb; ++i) {
-      Vec2 p;
-      float a;
-      int sel;
-      body(i, &p, &a, &sel);
-      Transform xf;
-      xf.p = p;
-      xf.q.Set(a);
-      ok = r.drawBody(&S->shapes[S->bodies[i].var[sel].shape], xf, (double)S->worldW, (double)S->lcdW) && ok;
-    }
-    r.write(lcdRow);
-  }
-  return ok;
-}
-
-template <int NB, int NJ, int NP>
-__global__ __launch_bounds__(kBlock) void step_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N,
-                                                      const int* __restrict__ eid, const float* __restrict__ actions,
-                                                      int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
-                                                      unsigned long long* __restrict__ waveTimes, long long actStride,
-                                                      uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut) {
-  unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
-  // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
-  // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
-  if ((int)threadIdx.x >= lanes) return;
-  int slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
-  if (slot >= N) return;
-  const int e = eid[slot];
-  Env<NB, NJ, NP> env;
-  env.load(S, st, N, slot);
-  env.profOn = waveTimes != nullptr;
-  if (S->dbgSkip & 8) {
-  } else if (nEnvSteps > 0) {
-    // Fused rollout: this wave advances its environments through all nEnvSteps on its own (no grid-wide barrier between
-    // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.
-    const size_t lcdRow = (size_t)S->lcdH * S->lcdW;
-    for (int t = 0; t < nEnvSteps; ++t) {
-      env.setMotorSpeeds(actions ? actions + (size_t)t * actStride : nullptr, N, e);
-      for (int k = 0; k < S->substeps; ++k) env.worldStep();
-      if (lcdOut || obsOut) {
-        auto body = [&](int i, Vec2* p, float* a, int* sel) {
-          const int bi = NB == 1 ? 0 : i;  // static index for single-body scenes (keeps env in registers)
-          *p = env.xfp[bi];
-          *a = env.a[bi];
-          *sel = env.sel[bi];
-        };
-        bool ok = emit_env<16, uint32_t, float>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr,
-                                                lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr);
-        if (!ok) env.fault |= FAULT_ELLIPSE;
-      }
-    }
-  } else {
-    if (setMotors) env.setMotorSpeeds(actions, N, e);
-    for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
-  }
-  env.checkFault();
-  env.store(st, N, slot);
-  if (waveTimes) {
-    // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
-    unsigned long long* o = waveTimes + (size_t)blockIdx.x * 9;
-    if (threadIdx.x == 0) o[0] = __builtin_amdgcn_s_memrealtime() - t0;
-    for (int k = 0; k < 8; ++k) atomicMax(&o[1 + k], env.prof[k]);
-  }
-}
 
 // world construction for the listed envs: b2World::CreateBody + CreateFixture (proxy: tight AABB +- aabbExtension, buffered
 // as moved, e_newFixture), revolute joints with referenceAngle = bodyB.angle - bodyA.angle.
@@ -190,40 +92,6 @@ __global__ void reset_kernel(const DevScene* __restrict__ S, float* __restrict__
   wp[(size_t)2 * N] = __uint_as_float((uint32_t)WF_NEWFIXTURE);
   wp[(size_t)3 * N] = __int_as_float(0);
   for (int k2 = 0; k2 < (np + 3) / 4; ++k2) wp[(size_t)(4 + k2) * N] = 0.0f;
-}
-
-// b2Body::SetTransform per masked body: position first, then angle (two calls, like `body.position=`; `body.angle=`),
-// each followed by proxy synchronisation with zero displacement; new contacts are looked for at the next step.
-template <int NB, int NJ, int NP>
-__global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ slotOf,
-                                 const int* __restrict__ idxs, int n, const float* __restrict__ poses,
-                                 const uint8_t* __restrict__ mask) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  int e = idxs ? idxs[k] : k;
-  if (e < 0 || e >= N) return;
-  e = slotOf[e];
-  Env<NB, NJ, NP> env;
-  env.load(S, st, N, e);
-  for (int i = 0; i < S->nb; ++i) {
-    if (mask && !mask[i]) continue;
-    const float* p = poses + ((size_t)k * S->nb + i) * 3;
-    for (int pass = 0; pass < 2; ++pass) {
-      float angle = pass == 0 ? env.a[i] : p[2];
-      Vec2 pos = pass == 0 ? V2(p[0], p[1]) : env.xfp[i];
-      env.q[i].Set(angle);
-      env.xfp[i] = pos;
-      Transform xf = env.xfOf(4 + i);
-      env.c[i] = Mul(xf, env.lc[i]);
-      env.a[i] = angle;
-      env.c0[i] = env.c[i];
-      env.a0[i] = angle;
-      env.synchronizeProxy(i, xf, xf);
-    }
-  }
-  // the reference's setters call FindNewContacts immediately; contacts are (A,B)-sorted here at the next step instead
-  env.wflags |= WF_NEWFIXTURE;
-  env.store(st, N, e);
 }
 
 template <int H, typename RowT, typename ObsT>
@@ -344,7 +212,10 @@ __global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restr
 // Re-binning: environments are independent, so WHERE an env's state lives is free.  Waves are 64 consecutive slots;
 // mixing asleep / free-flight / near-wall / touching envs in one wave leaves ~5 of 64 lanes active (measured, SQ PMC).
 // A stable counting sort of slots by work class makes waves homogeneous.  Stable => deterministic.
-//   class 0 asleep | 1 awake, no contact slot | 2 awake, contact slots, none touching | 3.. touching (by count)
+//   work 0 asleep | 1 awake, no contact slot | 2 awake, contact slots, none touching | 3.. touching (by count)
+// The sort key is kBins-1-work: the heaviest slots come FIRST.  Workgroups are dispatched in blockIdx order and a launch
+// has ~1.5x more waves than the chip has wave slots (occupancy 1), so heavy-first is longest-processing-time-first
+// scheduling: light waves backfill behind the heavy ones instead of the heavy ones starting last and forming the tail.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBins = 8;
 constexpr int kRebinBlock = 256;
@@ -353,15 +224,15 @@ __device__ inline int work_class(const DevScene* __restrict__ S, const float* __
   const int nb = S->nb, nj = S->nj, np = S->np;
   bool anyAwake = false;
   for (int i = 0; i < nb; ++i) anyAwake = anyAwake || st[(size_t)(i * kBodyFields + 12) * N + slot] != 0.0f;
-  if (!anyAwake) return 0;
+  if (!anyAwake) return kBins - 1;
   const float* pp = st + (size_t)(nb * kBodyFields) * N + slot;
   int nc = __float_as_int(pp[(size_t)(np * kPairFields + nj * kJointFields + 3) * N]);
-  if (nc == 0) return 1;
+  if (nc == 0) return kBins - 2;
   int touching = 0;
   for (int s2 = 0; s2 < np; ++s2)
     if (__float_as_int(pp[(size_t)(s2 * kPairFields) * N]) & PF_TOUCHING) ++touching;
   int c = 2 + touching;
-  return c < kBins ? c : kBins - 1;
+  return kBins - 1 - (c < kBins ? c : kBins - 1);
 }
 
 __global__ __launch_bounds__(kRebinBlock) void rebin_hist_kernel(const DevScene* __restrict__ S, const float* __restrict__ st,
@@ -710,18 +581,20 @@ static int out_done(blcd_handle h, int k, void* p, size_t bytes, void* dev) {
 }
 
 // ---- template dispatch over (max bodies, max joints, max pair slots) -------------------------------------
-#define BLCD_CONFIGS(X) X(1, 0, 4) X(2, 0, 9) X(3, 0, 15) X(4, 3, 16) X(5, 3, 24) X(7, 3, 44) X(20, 20, 100)
 struct Cfg {
-  int nb, nj, np;
+  int nb, nj, np, sh;
 };
 static const Cfg kCfgs[] = {
-#define X(a, b, c) {a, b, c},
+#define X(a, b, c, d) {a, b, c, d},
     BLCD_CONFIGS(X)
 #undef X
 };
 static int pick_cfg(const DevScene& S) {
+  bool circlesOnly = true;  // every variant of every dynamic body is a circle
+  for (int i = 0; i < S.nb; ++i)
+    for (int k = 0; k < S.bodies[i].nChoices; ++k) circlesOnly = circlesOnly && S.shapes[S.bodies[i].var[k].shape].type == kCircle;
   for (size_t i = 0; i < sizeof(kCfgs) / sizeof(kCfgs[0]); ++i)
-    if (S.nb <= kCfgs[i].nb && S.nj <= kCfgs[i].nj && S.np <= kCfgs[i].np) return (int)i;
+    if (S.nb <= kCfgs[i].nb && S.nj <= kCfgs[i].nj && S.np <= kCfgs[i].np && (kCfgs[i].sh == 0 || circlesOnly)) return (int)i;
   return -1;
 }
 
@@ -735,11 +608,10 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
     e1 = h->ev1;
   }
   HIPCHK(hipEventRecord(e0, h->stream));
+  StepArgs A{h->dScene, h->st, h->N, h->eid, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut};
   int idx = 0;
-#define X(a, b, c)                                                                                              \
-  if (h->cfg == idx)                                                                                            \
-    hipLaunchKernelGGL((step_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, h->eid, dActions, nEnvSteps, \
-                       nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut);                                                                 \
+#define X(a, b, c, d) \
+  if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, h->stream, A); \
   ++idx;
   BLCD_CONFIGS(X)
 #undef X
@@ -751,10 +623,10 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
 
 static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* dPoses, const uint8_t* dMask) {
   dim3 grid((n + 63) / 64), block(64);
+  SetPosesArgs A{h->dScene, h->st, h->N, h->slotOf, dIdx, n, dPoses, dMask};
   int idx = 0;
-#define X(a, b, c)                                                                                                  \
-  if (h->cfg == idx)                                                                                                \
-    hipLaunchKernelGGL((set_poses_kernel<a, b, c>), grid, block, 0, h->stream, h->dScene, h->st, h->N, h->slotOf, dIdx, n, dPoses, dMask); \
+#define X(a, b, c, d) \
+  if (h->cfg == idx) launch_set_poses_##a##_##b##_##c##_##d(grid, h->stream, A); \
   ++idx;
   BLCD_CONFIGS(X)
 #undef X

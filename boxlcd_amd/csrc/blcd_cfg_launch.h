@@ -1,0 +1,45 @@
+// blcd_cfg_launch.h — host-side launchers of the kernels that are specialised per scene-size class
+// (max bodies, max joints, max pair slots).  Each class is compiled in its own translation unit (blcd_cfg.hip with
+// -DBLCD_NB/-DBLCD_NJ/-DBLCD_NP) so that the classes build in parallel; blcd_api.hip dispatches on the handle's class.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "blcd_world.h"
+
+// X(max bodies, max joints, max pair slots, shape set): shape set 1 = circles-only scenes (see Env's SH parameter).
+// Order matters: the first class that fits the scene is used.
+#define BLCD_CONFIGS(X) \
+  X(1, 0, 4, 1) X(2, 0, 9, 1) X(1, 0, 4, 0) X(2, 0, 9, 0) X(3, 0, 15, 0) X(4, 3, 16, 0) X(5, 3, 24, 0) X(7, 3, 44, 0) X(20, 20, 100, 0)
+
+namespace blcd {
+
+struct StepArgs {
+  const DevScene* S;
+  float* st;
+  int N;
+  const int* eid;
+  const float* actions;
+  int nEnvSteps, nWorldSteps, setMotors, lanes;
+  unsigned long long* waveTimes;
+  long long actStride;
+  uint8_t* lcdOut;
+  float* obsOut;
+};
+struct SetPosesArgs {
+  const DevScene* S;
+  float* st;
+  int N;
+  const int* slotOf;
+  const int* idxs;
+  int n;
+  const float* poses;
+  const uint8_t* mask;
+};
+
+#define X(a, b, c, d)                                                                       \
+  void launch_step_##a##_##b##_##c##_##d(dim3 grid, hipStream_t stream, const StepArgs& A);    \
+  void launch_set_poses_##a##_##b##_##c##_##d(dim3 grid, hipStream_t stream, const SetPosesArgs& A);
+BLCD_CONFIGS(X)
+#undef X
+
+}  // namespace blcd

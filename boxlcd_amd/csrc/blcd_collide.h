@@ -194,11 +194,14 @@ BLCD_HD static inline void ShapeComputeMass(const Shape* s, MassData* md, float 
 }
 
 // b2{Circle,Polygon,Edge}Shape::ComputeAABB
+BLCD_HD static inline void CircleComputeAABB(const Shape* s, AABB* aabb, const Transform& xf) {
+  Vec2 p = xf.p + Mul(xf.q, s->v[0]);
+  aabb->lo = V2(p.x - s->radius, p.y - s->radius);
+  aabb->hi = V2(p.x + s->radius, p.y + s->radius);
+}
 BLCD_HD static inline void ShapeComputeAABB(const Shape* s, AABB* aabb, const Transform& xf) {
   if (s->type == kCircle) {
-    Vec2 p = xf.p + Mul(xf.q, s->v[0]);
-    aabb->lo = V2(p.x - s->radius, p.y - s->radius);
-    aabb->hi = V2(p.x + s->radius, p.y + s->radius);
+    CircleComputeAABB(s, aabb, xf);
     return;
   }
   if (s->type == kEdge) {

@@ -151,8 +151,9 @@ struct Raster {
   }
 
   // one body: boxLCD/world_env.py:493-505 (float64 `/ WIDTH * width`, then Pillow's (int) truncation)
+  template <bool CIRC = false>
   __device__ bool drawBody(const Shape* sh, const Transform& xf, double WIDTH, double width) {
-    if (sh->type == kCircle) {
+    if (CIRC || sh->type == kCircle) {
       double px = (double)xf.p.x, py = (double)xf.p.y, rad = (double)sh->radius;
       double tlx = (px - rad) / WIDTH * width, tly = (py - rad) / WIDTH * width;
       double brx = (px + rad) / WIDTH * width, bry = (py + rad) / WIDTH * width;

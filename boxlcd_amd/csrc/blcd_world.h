@@ -28,7 +28,7 @@ constexpr int kPairFields = 17;   // flags type|count ln.xy lp.xy {lp.xy ni ti i
 constexpr int kJointFields = 7;   // impulse.xyz motorImpulse limitState motorSpeed referenceAngle
 constexpr int kWorldFields = 4;   // inv_dt0 moveMask flags nc   (+ wl packed 4 slots per word)
 
-enum { PF_EXISTS = 1, PF_TOUCHING = 2, PF_ENABLED = 4, PF_ISLAND = 8, PF_TOI = 16 };
+enum { PF_EXISTS = 1, PF_TOUCHING = 2, PF_ENABLED = 4, PF_ISLAND = 8, PF_TOI = 16, PF_TOISKIP = 32 };
 enum { WF_NEWFIXTURE = 1 };
 enum { FAULT_NAN = 1, FAULT_ELLIPSE = 2, FAULT_OVERFLOW = 4 };
 enum { kInactiveLimit = 0, kAtLowerLimit = 1, kAtUpperLimit = 2, kEqualLimits = 3 };
@@ -167,8 +167,13 @@ struct ByteVec {
   }
 };
 
-template <int NB, int NJ, int NP>
+// SH = shape set of the scene, known when the handle is created: 0 = anything, 1 = every dynamic body is a circle.
+// Circles-only scenes (Bounce, Bounce2) get kernels without the polygon routines (edge-polygon / polygon-polygon collide,
+// 2-point manifolds and the block solver, polygon TOI proxies, polygon raster): far fewer live registers.
+template <int NB, int NJ, int NP, int SH = 0>
 struct Env {
+  static constexpr bool kCirc = SH == 1;
+  static constexpr int kMP = kCirc ? 1 : 2;  // manifold points a contact can have
   // Island contact capacity.  A single body in the walled arena can touch at most two (adjacent) walls at once, so the
   // one-body configuration keeps two constraint slots in registers; an island that would need more raises FAULT_OVERFLOW
   // (reported through blcd_get_faults) instead of silently dropping physics.
@@ -399,6 +404,7 @@ struct Env {
   // unchanged, only the sign of an exact zero could differ.  The body's stored transform (synchronizeTransform) is real.
   uint32_t deadQ;
   __device__ __forceinline__ Rot rotFor(int p, float angle) const { return rotDead(deadQ, p, angle); }
+  __device__ __forceinline__ int typeOf(int p) const { return p < 4 ? (int)kEdge : (kCirc ? (int)kCircle : (int)shapeOf(p)->type); }
   __device__ __forceinline__ const Shape* shapeOf(int p) const {
     if (p < 4) return &S->wallShape[p];
     int i = bi(p);
@@ -439,7 +445,7 @@ struct Env {
   __device__ __forceinline__ void slotAB(int s, int* pA, int* pB) const {
     int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
     if (pa_ >= 4) {
-      int ta = shapeOf(pa_)->type, tb = shapeOf(pb_)->type;
+      int ta = typeOf(pa_), tb = typeOf(pb_);
       // rank: polygon(1) before circle(0)  <=> swap when A is a circle and B a polygon
       if (ta == kCircle && tb == kPolygon) {
         int t = pa_;
@@ -457,8 +463,13 @@ struct Env {
   __device__ __forceinline__ void synchronizeProxy(int i, const Transform& xf1, const Transform& xf2) {
     const Shape* sh = shapeOf(4 + i);
     AABB aabb1, aabb2, aabb;
-    ShapeComputeAABB(sh, &aabb1, xf1);
-    ShapeComputeAABB(sh, &aabb2, xf2);
+    if (kCirc) {
+      CircleComputeAABB(sh, &aabb1, xf1);
+      CircleComputeAABB(sh, &aabb2, xf2);
+    } else {
+      ShapeComputeAABB(sh, &aabb1, xf1);
+      ShapeComputeAABB(sh, &aabb2, xf2);
+    }
     aabb.lo = Min(aabb1.lo, aabb2.lo);
     aabb.hi = Max(aabb1.hi, aabb2.hi);
     Vec2 displacement = xf2.p - xf1.p;
@@ -517,7 +528,7 @@ struct Env {
     const Shape* shA = shapeOf(pA);
     const Shape* shB = shapeOf(pB);
     Transform xfA = xfOf(pA), xfB = xfOf(pB);
-    int ta = shA->type, tb = shB->type;
+    int ta = typeOf(pA), tb = typeOf(pB);
     if (ta == kEdge) {
       if (tb == kCircle) CollideEdgeAndCircle(&m, shA, xfA, shB, xfB);
       else CollideEdgeAndPolygon(&m, shA, xfA, shB, xfB);
@@ -529,14 +540,14 @@ struct Env {
     }
     bool touching = m.pointCount > 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kMP; ++i) {
       if (i >= m.pointCount) break;
       ManifoldPoint* mp2 = m.points + i;
       mp2->normalImpulse = 0.0f;
       mp2->tangentImpulse = 0.0f;
       uint32_t key = mp2->id.key;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kMP; ++j) {
         if (j >= oldManifold.pointCount) break;
         const ManifoldPoint* mp1 = oldManifold.points + j;
         if (mp1->id.key == key) {
@@ -622,7 +633,7 @@ struct Env {
       c_.K.ex = c_.K.ey = V2(0.0f, 0.0f);
       c_.normalMass.ex = c_.normalMass.ey = V2(0.0f, 0.0f);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kMP; ++j) {
         if (j >= m.pointCount) break;
         VCPoint& p = c_.points[j];
         if (warmStarting) {
@@ -670,7 +681,7 @@ struct Env {
       c_.normal = worldManifold.normal;
       int pointCount = c_.pointCount;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kMP; ++j) {
         if (j >= pointCount) break;
         VCPoint* vcp = c_.points + j;
         vcp->rA = worldManifold.points[j] - cA;
@@ -688,7 +699,7 @@ struct Env {
         float vRel = Dot(c_.normal, vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA));
         if (vRel < -kVelocityThreshold) vcp->velocityBias = -c_.restitution * vRel;
       }
-      if (c_.pointCount == 2) {
+      if (kMP == 2 && c_.pointCount == 2) {
         VCPoint* vcp1 = c_.points + 0;
         VCPoint* vcp2 = c_.points + 1;
         float rn1A = Cross(vcp1->rA, c_.normal);
@@ -724,7 +735,7 @@ struct Env {
       Vec2 normal = c_.normal;
       Vec2 tangent = Cross(normal, 1.0f);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kMP; ++j) {
         if (j >= c_.pointCount) break;
         VCPoint* vcp = c_.points + j;
         Vec2 P = vcp->normalImpulse * normal + vcp->tangentImpulse * tangent;
@@ -758,7 +769,7 @@ struct Env {
       Vec2 tangent = Cross(normal, 1.0f);
       float friction = c_.friction;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kMP; ++j) {
         if (j >= pointCount) break;
         VCPoint* vcp = c_.points + j;
         Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
@@ -775,7 +786,7 @@ struct Env {
         vB += mB * P;
         wB += iB * Cross(vcp->rB, P);
       }
-      if (pointCount == 1) {
+      if (kMP == 1 || pointCount == 1) {
         VCPoint* vcp = c_.points + 0;
         Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
         float vn = Dot(dv, normal);
@@ -851,7 +862,7 @@ struct Env {
       VC& c_ = vc[i];
       Manifold m = selGet(man, c_.slot);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kMP; ++j) {
         if (j < c_.pointCount) {
           m.points[j].normalImpulse = c_.points[j].normalImpulse;
           m.points[j].tangentImpulse = c_.points[j].tangentImpulse;
@@ -889,7 +900,7 @@ struct Env {
       Vec2 cB = Pc(pB);
       float aB = Pa(pB);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kMP; ++j) {
         if (j >= pointCount) break;
         Transform xfA, xfB;
         xfA.q = rotFor(pA, aA);
@@ -1183,7 +1194,7 @@ struct Env {
       if (k < nic) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          bool live = j < vc[k].pointCount;
+          bool live = j < kMP && j < vc[k].pointCount;
           dst.v[3 * kCycNB + 4 * k + 2 * j] = live ? vc[k].points[j].normalImpulse : 0.0f;
           dst.v[3 * kCycNB + 4 * k + 2 * j + 1] = live ? vc[k].points[j].tangentImpulse : 0.0f;
         }
@@ -1203,7 +1214,7 @@ struct Env {
     for (int k = 0; k < kCycNC; ++k) {
       if (k < nic) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < kMP; ++j) {
           if (j < vc[k].pointCount) {
             vc[k].points[j].normalImpulse = src.v[3 * kCycNB + 4 * k + 2 * j];
             vc[k].points[j].tangentImpulse = src.v[3 * kCycNB + 4 * k + 2 * j + 1];
@@ -1678,11 +1689,73 @@ struct Env {
     for (int k = 0; k < 4; ++k) wallAlpha0[k] = 0.0f;
     for (int k = 0; k < nc; ++k) {
       int s = wl.get(k);
-      pflags.clearBits(s, PF_TOI | PF_ISLAND);
+      pflags.clearBits(s, PF_TOI | PF_ISLAND | PF_TOISKIP);
       toiCount.set(s, 0);
       selSet(toi, s, (float)(1.0f));
     }
     for (int guard = 0; guard < 64 * (NP + 1); ++guard) {
+      for (int k = 0; k < nc; ++k) {
+        int s = wl.get(k);
+        if (pflags.get(s) & PF_TOISKIP) pflags.clearBits(s, PF_TOI | PF_TOISKIP);
+      }
+      // Phase 1: every contact whose TOI is not cached gets it computed, in contact-list order per environment.  Each
+      // lane jumps straight to ITS next pending contact, so a wave runs the (long) TOI routine max-over-lanes(#pending)
+      // times instead of once per list position at which any lane is pending.  Same per-environment operation order as
+      // the reference's single loop: cached entries are only read, and they are read in phase 2.
+      for (;;) {
+        int s = -1, fl = 0;
+        for (int k = 0; k < nc; ++k) {
+          int s2 = wl.get(k);
+          int f2 = pflags.get(s2);
+          bool pending = s < 0 && (f2 & PF_ENABLED) && !(f2 & PF_TOI) && toiCount.get(s2) <= kMaxSubSteps;
+          if (pending) {
+            s = s2;
+            fl = f2;
+          }
+        }
+        if (s < 0) break;
+        float alpha = 1.0f;
+        int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+        int b = pa_ >= 4 ? 0 : bi(pb_);
+        if (pa_ >= 4 || !awakeDyn(b)) {
+          // two non-bullet dynamic bodies, or nothing awake: the reference skips the contact without caching anything.
+          // The verdict is remembered for THIS pass only (so the scan moves on) and dropped before the next pass.
+          selSet(toi, s, 1.0f);
+          pflags.set(s, fl | PF_TOI | PF_TOISKIP);
+          continue;
+        }
+        // put the sweeps onto the same time interval (the wall's alpha0 is part of the state, see b2World::SolveTOI)
+        float alpha0_ = selGet(wallAlpha0, pa_);
+        if (alpha0_ < alpha0[b]) {
+          alpha0_ = alpha0[b];
+          selSet(wallAlpha0, pa_, alpha0_);  // wall sweep Advance: c0 = c = 0 stays, alpha0 moves
+        } else if (alpha0[b] < alpha0_) {
+          Sweep sw = sweepOf(pb_);
+          sw.Advance(alpha0_);
+          c0[b] = sw.c0;
+          a0[b] = sw.a0;
+          alpha0[b] = sw.alpha0;
+        }
+        TOIOutput output;
+        {
+          // wall edge vs moving shape, everything in registers (blcd_toi_wall.h); the proxy width follows the shape so
+          // that circles and boxes do not pay for 8-vertex select chains
+          const Shape* shB = shapeOf(pb_);
+          const Vec2 e0 = S->wallShape[pa_].v[0], e1 = S->wallShape[pa_].v[1];
+          const float er = S->wallShape[pa_].radius;
+          const int nv = (kCirc || shB->type == kCircle) ? 1 : shB->count;
+          if (nv == 1) toiWallRun<1>(&output, e0, e1, er, shB, sweepOf(pb_));
+          else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
+          else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
+        }
+        prof[4] += 1;
+        float beta = output.t;
+        if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
+        else alpha = 1.0f;
+        selSet(toi, s, (float)(alpha));
+        pflags.set(s, fl | PF_TOI);
+      }
+      // Phase 2: the minimum over the contact list (first minimum wins, as in the reference's `alpha < minAlpha`)
       int minSlot = -1;
       float minAlpha = 1.0f;
       for (int k = 0; k < nc; ++k) {
@@ -1690,45 +1763,8 @@ struct Env {
         int fl = pflags.get(s);
         if (!(fl & PF_ENABLED)) continue;
         if (toiCount.get(s) > kMaxSubSteps) continue;
-        float alpha = 1.0f;
-        if (fl & PF_TOI) {
-          alpha = selGet(toi, s);
-        } else {
-          int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
-          if (pa_ >= 4) continue;  // two non-bullet dynamic bodies
-          int b = bi(pb_);
-          if (!awakeDyn(b)) continue;
-          // put the sweeps onto the same time interval (the wall's alpha0 is part of the state, see b2World::SolveTOI)
-          float alpha0_ = selGet(wallAlpha0, pa_);
-          if (alpha0_ < alpha0[b]) {
-            alpha0_ = alpha0[b];
-            selSet(wallAlpha0, pa_, alpha0_);  // wall sweep Advance: c0 = c = 0 stays, alpha0 moves
-          } else if (alpha0[b] < alpha0_) {
-            Sweep sw = sweepOf(pb_);
-            sw.Advance(alpha0_);
-            c0[b] = sw.c0;
-            a0[b] = sw.a0;
-            alpha0[b] = sw.alpha0;
-          }
-          TOIOutput output;
-          {
-            // wall edge vs moving shape, everything in registers (blcd_toi_wall.h); the proxy width follows the shape so
-            // that circles and boxes do not pay for 8-vertex select chains
-            const Shape* shB = shapeOf(pb_);
-            const Vec2 e0 = S->wallShape[pa_].v[0], e1 = S->wallShape[pa_].v[1];
-            const float er = S->wallShape[pa_].radius;
-            const int nv = shB->type == kCircle ? 1 : shB->count;
-            if (nv == 1) toiWallRun<1>(&output, e0, e1, er, shB, sweepOf(pb_));
-            else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
-            else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
-          }
-          prof[4] += 1;
-          float beta = output.t;
-          if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
-          else alpha = 1.0f;
-          selSet(toi, s, (float)(alpha));
-          pflags.set(s, fl | PF_TOI);
-        }
+        if (fl & PF_TOISKIP) continue;
+        float alpha = selGet(toi, s);
         if (alpha < minAlpha) {
           minSlot = s;
           minAlpha = alpha;
@@ -1817,7 +1853,7 @@ struct Env {
       synchronizeFixtures(b);
       for (int k = 0; k < nc; ++k) {
         int s = wl.get(k);
-        if (S->pairs[s].a == pB || S->pairs[s].b == pB) pflags.clearBits(s, PF_TOI | PF_ISLAND);
+        if (S->pairs[s].a == pB || S->pairs[s].b == pB) pflags.clearBits(s, PF_TOI | PF_ISLAND | PF_TOISKIP);
       }
       findNewContacts(false);
       if (profOn) prof[3] += __builtin_amdgcn_s_memtime() - e0_;
@@ -1833,7 +1869,11 @@ struct Env {
     float dt = S->dt;
     float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
     float dtRatio = inv_dt0 * dt;
+#ifdef BLCD_CT_SKIP
+    const int skip = BLCD_CT_SKIP;   // compile-time phase removal: register-pressure experiments only
+#else
     const int skip = S->dbgSkip;
+#endif
     unsigned long long c0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
     if (!(skip & 1)) collide();
     unsigned long long c1_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
