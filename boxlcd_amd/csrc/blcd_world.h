@@ -211,6 +211,14 @@ struct Env {
   uint32_t wflags;
   int fault;
   float wallAlpha0[4];
+  // Scene constants the hot loops ask for with per-lane indices, copied to registers once per launch: a per-lane-indexed read
+  // of DevScene is a vector global load (hundreds of cycles at one wave per SIMD) in the middle of a dependent chain.
+  Vec2 wallV0[4], wallV1[4];                 // the four wall edges (wave-uniform)
+  float wallRad[4];
+  static constexpr bool kPairRegs = NP <= 4;   // ByteVec packs up to 4 entries into one register
+  ByteVec<4> pairA_, pairB_;                 // pair table (proxy ids), one-body classes
+  float crad[kCirc ? NB : 1];                // circles-only scenes: the bodies' shapes
+  Vec2 cctr[kCirc ? NB : 1];
   // diagnostic per-wave cycle accounting (BLCD_WAVETIMES): 0 collide 1 solve 2 toi-search 3 toi-event 4 #toi calls 5 #events 6 sweeps 7 posIters
   unsigned long long prof[8];
   bool profOn;
@@ -236,6 +244,19 @@ struct Env {
     const int nb = S->nb, nj = S->nj, np = S->np;
     awakeMask = 0;
     deadQ = 15u;
+    for (int k = 0; k < 4; ++k) {
+      wallV0[k] = S->wallShape[k].v[0];
+      wallV1[k] = S->wallShape[k].v[1];
+      wallRad[k] = S->wallShape[k].radius;
+    }
+    pairA_.w = pairB_.w = 0;
+    if (kPairRegs) {
+#pragma unroll
+      for (int s2 = 0; s2 < (kPairRegs ? NP : 0); ++s2) {
+        pairA_.set(s2, s2 < np ? S->pairs[s2].a : 0);
+        pairB_.set(s2, s2 < np ? S->pairs[s2].b : 0);
+      }
+    }
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
       const float* p = st + (size_t)(i * kBodyFields) * N + e;
@@ -258,6 +279,10 @@ struct Env {
       invI[i] = var.invI;
       lc[i] = var.localCenter;
       const Shape& shp = S->shapes[var.shape];
+      if (kCirc) {
+        crad[i] = shp.radius;
+        cctr[i] = shp.v[0];
+      }
       if (shp.type == kCircle && shp.v[0].x == 0.0f && shp.v[0].y == 0.0f && lc[i].x == 0.0f && lc[i].y == 0.0f) deadQ |= 16u << i;
     }
     const float* pp = st + (size_t)(nb * kBodyFields) * N + e;
@@ -404,6 +429,30 @@ struct Env {
   // unchanged, only the sign of an exact zero could differ.  The body's stored transform (synchronizeTransform) is real.
   uint32_t deadQ;
   __device__ __forceinline__ Rot rotFor(int p, float angle) const { return rotDead(deadQ, p, angle); }
+  __device__ __forceinline__ int pairAOf(int s) const { return kPairRegs ? pairA_.get(s) : S->pairs[s].a; }
+  __device__ __forceinline__ int pairBOf(int s) const { return kPairRegs ? pairB_.get(s) : S->pairs[s].b; }
+  __device__ __forceinline__ Shape wallShapeReg(int p) const {  // only type/radius/count/v[0..1] are meaningful
+    Shape w{};
+    w.type = kEdge;
+    w.count = 2;
+    w.radius = selGet(wallRad, p);
+    w.v[0] = selGet(wallV0, p);
+    w.v[1] = selGet(wallV1, p);
+    return w;
+  }
+  __device__ __forceinline__ Shape circShapeReg(int i) const {  // kCirc only
+    Shape c_{};
+    c_.type = kCircle;
+    c_.count = 1;
+    c_.radius = crad[NB == 1 ? 0 : i];
+    c_.v[0] = cctr[NB == 1 ? 0 : i];
+    return c_;
+  }
+  __device__ __forceinline__ float radiusOf(int p) const {
+    if (p < 4) return selGet(wallRad, p);
+    if (kCirc) return circShapeReg(bi(p)).radius;
+    return shapeOf(p)->radius;
+  }
   __device__ __forceinline__ int typeOf(int p) const { return p < 4 ? (int)kEdge : (kCirc ? (int)kCircle : (int)shapeOf(p)->type); }
   __device__ __forceinline__ const Shape* shapeOf(int p) const {
     if (p < 4) return &S->wallShape[p];
@@ -443,7 +492,7 @@ struct Env {
   }
   // fixture order of a slot after b2Contact::Create's type normalisation
   __device__ __forceinline__ void slotAB(int s, int* pA, int* pB) const {
-    int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+    int pa_ = pairAOf(s), pb_ = pairBOf(s);
     if (pa_ >= 4) {
       int ta = typeOf(pa_), tb = typeOf(pb_);
       // rank: polygon(1) before circle(0)  <=> swap when A is a circle and B a polygon
@@ -461,12 +510,13 @@ struct Env {
   // broad phase: b2Fixture::Synchronize + b2DynamicTree::MoveProxy, b2BroadPhase::UpdatePairs, AddPair
   // ------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void synchronizeProxy(int i, const Transform& xf1, const Transform& xf2) {
-    const Shape* sh = shapeOf(4 + i);
     AABB aabb1, aabb2, aabb;
     if (kCirc) {
-      CircleComputeAABB(sh, &aabb1, xf1);
-      CircleComputeAABB(sh, &aabb2, xf2);
+      const Shape cs = circShapeReg(i);
+      CircleComputeAABB(&cs, &aabb1, xf1);
+      CircleComputeAABB(&cs, &aabb2, xf2);
     } else {
+      const Shape* sh = shapeOf(4 + i);
       ShapeComputeAABB(sh, &aabb1, xf1);
       ShapeComputeAABB(sh, &aabb2, xf2);
     }
@@ -499,7 +549,7 @@ struct Env {
     for (int s = 0; s < NP; ++s) {
       if (s >= np) break;
       if (pflags.get(s) & PF_EXISTS) continue;
-      int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+      int pa_ = pairAOf(s), pb_ = pairBOf(s);
       bool moved = allMoved || (pa_ >= 4 && ((mm >> (pa_ - 4)) & 1)) || ((mm >> (pb_ - 4)) & 1);
       if (!moved) continue;
       if (!TestOverlap(fatOf(pa_), fatOf(pb_))) continue;
@@ -525,18 +575,26 @@ struct Env {
     Manifold oldManifold = m;
     pflags.orBits(s, PF_ENABLED);
     bool wasTouching = (pflags.get(s) & PF_TOUCHING) != 0;
-    const Shape* shA = shapeOf(pA);
-    const Shape* shB = shapeOf(pB);
     Transform xfA = xfOf(pA), xfB = xfOf(pB);
     int ta = typeOf(pA), tb = typeOf(pB);
     if (ta == kEdge) {
-      if (tb == kCircle) CollideEdgeAndCircle(&m, shA, xfA, shB, xfB);
-      else CollideEdgeAndPolygon(&m, shA, xfA, shB, xfB);
+      const Shape wA = wallShapeReg(pA);
+      if (kCirc) {
+        const Shape cB = circShapeReg(bi(pB));
+        CollideEdgeAndCircle(&m, &wA, xfA, &cB, xfB);
+      } else if (tb == kCircle) {
+        CollideEdgeAndCircle(&m, &wA, xfA, shapeOf(pB), xfB);
+      } else {
+        CollideEdgeAndPolygon(&m, &wA, xfA, shapeOf(pB), xfB);
+      }
     } else if (ta == kPolygon) {
-      if (tb == kCircle) CollidePolygonAndCircle(&m, shA, xfA, shB, xfB);
-      else CollidePolygons(&m, shA, xfA, shB, xfB);
+      if (tb == kCircle) CollidePolygonAndCircle(&m, shapeOf(pA), xfA, shapeOf(pB), xfB);
+      else CollidePolygons(&m, shapeOf(pA), xfA, shapeOf(pB), xfB);
+    } else if (kCirc) {
+      const Shape cA = circShapeReg(bi(pA)), cB = circShapeReg(bi(pB));
+      CollideCircles(&m, &cA, xfA, &cB, xfB);
     } else {
-      CollideCircles(&m, shA, xfA, shB, xfB);
+      CollideCircles(&m, shapeOf(pA), xfA, shapeOf(pB), xfB);
     }
     bool touching = m.pointCount > 0;
 #pragma unroll
@@ -569,7 +627,7 @@ struct Env {
     int n = nc, out = 0;
     for (int k = 0; k < n; ++k) {
       int s = wl.get(k);
-      int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+      int pa_ = pairAOf(s), pb_ = pairBOf(s);
       bool activeA = pa_ >= 4 && awakeDyn(pa_ - 4);
       bool activeB = awakeDyn(pb_ - 4);
       if (activeA || activeB) {
@@ -660,7 +718,7 @@ struct Env {
       const Manifold mcopy = selGet(man, c_.slot);
       const Manifold* manifold = &mcopy;
       int pA = c_.pA, pB = c_.pB;
-      float radiusA = shapeOf(pA)->radius, radiusB = shapeOf(pB)->radius;
+      float radiusA = radiusOf(pA), radiusB = radiusOf(pB);
       float mA = mOf(pA), mB = mOf(pB), iA = iOf(pA), iB = iOf(pB);
       Vec2 localCenterA = lcOf(pA), localCenterB = lcOf(pB);
       Vec2 cA = Pc(pA);
@@ -893,7 +951,7 @@ struct Env {
           iB = 0.0f;
         }
       }
-      float radiusA = shapeOf(pA)->radius, radiusB = shapeOf(pB)->radius;
+      float radiusA = radiusOf(pA), radiusB = radiusOf(pB);
       int pointCount = m.pointCount;
       Vec2 cA = Pc(pA);
       float aA = Pa(pA);
@@ -1341,8 +1399,8 @@ struct Env {
         c_.localPoint = m.localPoint;
         c_.lp0 = m.points[0].localPoint;
         c_.lp1 = m.points[1].localPoint;
-        c_.radiusA = shapeOf(c_.pA)->radius;
-        c_.radiusB = shapeOf(c_.pB)->radius;
+        c_.radiusA = radiusOf(c_.pA);
+        c_.radiusB = radiusOf(c_.pB);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           RPoint& p = c_.points[j];
@@ -1599,7 +1657,7 @@ struct Env {
         wake(p);
         for (int k = 0; k < nc; ++k) {  // contact-edge list of b == world list filtered by b (same relative order)
           int s = wl.get(k);
-          int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+          int pa_ = pairAOf(s), pb_ = pairBOf(s);
           if (pa_ != p && pb_ != p) continue;
           int fl = pflags.get(s);
           if (fl & PF_ISLAND) continue;
@@ -1715,7 +1773,7 @@ struct Env {
         }
         if (s < 0) break;
         float alpha = 1.0f;
-        int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+        int pa_ = pairAOf(s), pb_ = pairBOf(s);
         int b = pa_ >= 4 ? 0 : bi(pb_);
         if (pa_ >= 4 || !awakeDyn(b)) {
           // two non-bullet dynamic bodies, or nothing awake: the reference skips the contact without caching anything.
@@ -1737,18 +1795,45 @@ struct Env {
           alpha0[b] = sw.alpha0;
         }
         TOIOutput output;
-        {
+        // Exact early-out for circles centred on their body origin (deadQ): b2TimeOfImpact's first iteration returns
+        // e_separated, t = tMax when (1) b2Distance at t1 = 0 is >= target + tolerance and (2) the separation at tMax along
+        // the axis it then picks is > target + tolerance.  For a one-vertex proxy against a wall whose segment the centre
+        // projects well inside, GJK ends on the face (both edge vertices), the axis is the wall normal, and both numbers are
+        // the centre's signed distance to the wall line at c0 and at c.  If both clear the threshold by a margin (5e-4,
+        // ~500x the float error of either evaluation) on the same side, the routine's answer is known without running it.
+        bool knownSeparated = false;
+        if ((deadQ >> pb_) & 1u) {
+          const Vec2 w0 = selGet(wallV0, pa_), w1 = selGet(wallV1, pa_);
+          const float totalRadius = selGet(wallRad, pa_) + radiusOf(pb_);
+          const float thr = Max(kLinearSlop, totalRadius - 3.0f * kLinearSlop) + 0.25f * kLinearSlop + 5.0e-4f;
+          const Vec2 ed = w1 - w0;
+          const float len2 = Dot(ed, ed);
+          const float inv = 1.0f / sqrtf(len2);
+          const Vec2 r0 = c0[b] - w0, r1 = c[b] - w0;
+          const float d0 = Cross(ed, r0) * inv, d1 = Cross(ed, r1) * inv;
+          const float u = Dot(r0, ed) / len2;
+          knownSeparated = u > 0.01f && u < 0.99f && ((d0 > thr && d1 > thr) || (d0 < -thr && d1 < -thr));
+        }
+        if (knownSeparated) {
+          output.state = kTOISeparated;
+          output.t = 1.0f;
+        } else {
           // wall edge vs moving shape, everything in registers (blcd_toi_wall.h); the proxy width follows the shape so
           // that circles and boxes do not pay for 8-vertex select chains
-          const Shape* shB = shapeOf(pb_);
-          const Vec2 e0 = S->wallShape[pa_].v[0], e1 = S->wallShape[pa_].v[1];
-          const float er = S->wallShape[pa_].radius;
-          const int nv = (kCirc || shB->type == kCircle) ? 1 : shB->count;
-          if (nv == 1) toiWallRun<1>(&output, e0, e1, er, shB, sweepOf(pb_));
-          else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
-          else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
+          const Vec2 e0 = selGet(wallV0, pa_), e1 = selGet(wallV1, pa_);
+          const float er = selGet(wallRad, pa_);
+          if (kCirc) {
+            const Shape cB = circShapeReg(b);
+            toiWallRun<1>(&output, e0, e1, er, &cB, sweepOf(pb_));
+          } else {
+            const Shape* shB = shapeOf(pb_);
+            const int nv = shB->type == kCircle ? 1 : shB->count;
+            if (nv == 1) toiWallRun<1>(&output, e0, e1, er, shB, sweepOf(pb_));
+            else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
+            else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
+          }
+          prof[4] += 1;
         }
-        prof[4] += 1;
         float beta = output.t;
         if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
         else alpha = 1.0f;
@@ -1772,8 +1857,8 @@ struct Env {
       }
       if (minSlot < 0 || 1.0f - 10.0f * kEpsilon < minAlpha) break;
 
-      const int wA = S->pairs[minSlot].a;      // wall (fixture A)
-      const int pB = S->pairs[minSlot].b;
+      const int wA = pairAOf(minSlot);      // wall (fixture A)
+      const int pB = pairBOf(minSlot);
       const int b = bi(pB);
       // backups
       float backupWallAlpha = selGet(wallAlpha0, wA);
@@ -1807,7 +1892,7 @@ struct Env {
       for (int k = 0; k < nc; ++k) {
         if (nic == kMaxTOIContacts) break;
         int s = wl.get(k);
-        int pa_ = S->pairs[s].a, pb_ = S->pairs[s].b;
+        int pa_ = pairAOf(s), pb_ = pairBOf(s);
         if (pa_ != pB && pb_ != pB) continue;
         if (pflags.get(s) & PF_ISLAND) continue;
         int other = pa_ == pB ? pb_ : pa_;
@@ -1853,7 +1938,7 @@ struct Env {
       synchronizeFixtures(b);
       for (int k = 0; k < nc; ++k) {
         int s = wl.get(k);
-        if (S->pairs[s].a == pB || S->pairs[s].b == pB) pflags.clearBits(s, PF_TOI | PF_ISLAND | PF_TOISKIP);
+        if (pairAOf(s) == pB || pairBOf(s) == pB) pflags.clearBits(s, PF_TOI | PF_ISLAND | PF_TOISKIP);
       }
       findNewContacts(false);
       if (profOn) prof[3] += __builtin_amdgcn_s_memtime() - e0_;
