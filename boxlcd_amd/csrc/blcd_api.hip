@@ -506,7 +506,7 @@ struct blcd_handle_s {
   int *binCounts = nullptr, *binOffsets = nullptr;
   int rebinEvery = 0;       // 0 = never; k = after every k-th env step
   int lanes = 64;           // environments per wave in step_kernel (BLCD_LANES)
-  int rolloutChunk = 50;    // env steps per fused rollout launch (BLCD_CHUNK; 0 = one launch per step + separate obs kernel)
+  int rolloutChunk = 20;    // env steps per fused rollout launch (BLCD_CHUNK; 0 = one launch per step + separate obs kernel)
   unsigned long long* waveTimes = nullptr;  // per-wave duration of the last step launch (diagnostic, BLCD_WAVETIMES=1)
   int stepsSinceRebin = 0;
   size_t words = 0;

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
     unsigned long long* o = waveTimes + (size_t)blockIdx.x * 9;
     if (threadIdx.x == 0) o[0] = __builtin_amdgcn_s_memrealtime() - t0;
-    for (int k = 0; k < 8; ++k) atomicMax(&o[1 + k], env.prof[k]);
+    for (int k = 0; k < 6; ++k) atomicMax(&o[1 + k], env.prof[k]);
+    for (int k = 6; k < 8; ++k) atomicAdd(&o[1 + k], env.prof[k]);
   }
 }
 
@@ -84,7 +85,7 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
     for (int pass = 0; pass < 2; ++pass) {
       float angle = pass == 0 ? env.a[i] : p[2];
       Vec2 pos = pass == 0 ? V2(p[0], p[1]) : env.xfp[i];
-      env.q[i].Set(angle);
+      env.q[i] = env.rotFor(4 + i, angle);
       env.xfp[i] = pos;
       Transform xf = env.xfOf(4 + i);
       env.c[i] = Mul(xf, env.lc[i]);

@@ -219,7 +219,7 @@ struct Env {
   ByteVec<4> pairA_, pairB_;                 // pair table (proxy ids), one-body classes
   float crad[kCirc ? NB : 1];                // circles-only scenes: the bodies' shapes
   Vec2 cctr[kCirc ? NB : 1];
-  // diagnostic per-wave cycle accounting (BLCD_WAVETIMES): 0 collide 1 solve 2 toi-search 3 toi-event 4 #toi calls 5 #events 6 sweeps 7 posIters
+  // diagnostic per-wave cycle accounting (BLCD_WAVETIMES): 0 collide 1 solve 2 toi (all) 3 toi-event 4 #toi calls 5 #events | summed over lanes: 6 cycles inside the TOI routine, 7 wave-level executions of it
   unsigned long long prof[8];
   bool profOn;
   // --- island scratch ---
@@ -272,7 +272,6 @@ struct Env {
       fat[i].lo = V2(p[(size_t)13 * N], p[(size_t)14 * N]);
       fat[i].hi = V2(p[(size_t)15 * N], p[(size_t)16 * N]);
       sel[i] = __float_as_int(p[(size_t)17 * N]);
-      q[i].Set(a[i]);
       alpha0[i] = 0.0f;
       const DevVariant& var = S->bodies[i].var[sel[i]];
       invMass[i] = var.invMass;
@@ -283,7 +282,10 @@ struct Env {
         crad[i] = shp.radius;
         cctr[i] = shp.v[0];
       }
-      if (shp.type == kCircle && shp.v[0].x == 0.0f && shp.v[0].y == 0.0f && lc[i].x == 0.0f && lc[i].y == 0.0f) deadQ |= 16u << i;
+      if (shp.type == kCircle && shp.v[0].x == 0.0f && shp.v[0].y == 0.0f && lc[i].x == 0.0f && lc[i].y == 0.0f &&
+          S->bodies[i].nJoints == 0)   // a joint anchor would make the rotation matter
+        deadQ |= 16u << i;
+      q[i] = rotFor(4 + i, a[i]);   // the stored rotation is itself only consumed by contact code (see rotFor)
     }
     const float* pp = st + (size_t)(nb * kBodyFields) * N + e;
 #pragma unroll kUS
@@ -426,7 +428,8 @@ struct Env {
   // Rotation used by the CONTACT code for proxy p at angle `angle`.  Walls sit at angle 0 (sincosf(0) == (0, 1) exactly).
   // For a circle centred on its body origin, with the centre of mass there too, every contact-side use of q multiplies the
   // zero vector (xf.p = c - q*localCenter; manifold local points are the circle centre), so sincosf is skipped: values are
-  // unchanged, only the sign of an exact zero could differ.  The body's stored transform (synchronizeTransform) is real.
+  // unchanged, only the sign of an exact zero could differ.  This includes the body's stored rotation q[i]: it is not part
+  // of the persistent state (observations and the raster recompute sin/cos from the angle) and is read by contact code only.
   uint32_t deadQ;
   __device__ __forceinline__ Rot rotFor(int p, float angle) const { return rotDead(deadQ, p, angle); }
   __device__ __forceinline__ int pairAOf(int s) const { return kPairRegs ? pairA_.get(s) : S->pairs[s].a; }
@@ -487,7 +490,7 @@ struct Env {
     w[i] = 0.0f;
   }
   __device__ __forceinline__ void syncTransform(int i) {  // b2Body::SynchronizeTransform
-    q[i].Set(a[i]);
+    q[i] = rotFor(4 + i, a[i]);
     xfp[i] = c[i] - Mul(q[i], lc[i]);
   }
   // fixture order of a slot after b2Contact::Create's type normalisation
@@ -1289,7 +1292,6 @@ struct Env {
       bool changed = false;
       for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
       changed = csSolveVelocityConstraints(nic) || changed;
-      prof[6] += 1;
       if (!changed) break;
       if (watch && it < kCycSweeps) {
         CycRow cur;
@@ -1445,7 +1447,6 @@ struct Env {
       }
     }
     int sweeps = R.velocitySweeps(S->velIters, h);
-    prof[6] += sweeps;
     // b2ContactSolver::StoreImpulses
 #pragma unroll
     for (int k = 0; k < kRegC; ++k) {
@@ -1489,7 +1490,6 @@ struct Env {
     }
     int pit = 0;
     bool positionSolved = R.positionIterations(S->posIters, &pit);
-    prof[7] += pit;
     // copy back
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -1570,7 +1570,6 @@ struct Env {
     const int posIters = S->posIters;
     for (int it = 0; it < posIters; ++it) {
       float minSeparation = csSolvePosition(nic, false, -1);
-      prof[7] += 1;
       bool contactsOkay = minSeparation >= -3.0f * kLinearSlop;
       bool jointsOkay = true;
       for (int k = 0; k < nij; ++k) {
@@ -1736,11 +1735,17 @@ struct Env {
     alpha0[i] = sw.alpha0;
     c[i] = c0[i];
     a[i] = a0[i];
-    q[i].Set(a[i]);
+    q[i] = rotFor(4 + i, a[i]);
     xfp[i] = c[i] - Mul(q[i], lc[i]);
   }
 
   __device__ __forceinline__ void solveTOI(float dt) {
+#ifdef BLCD_PROF_TOI
+#define PT(k_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[k_] += n_ - pt_; pt_ = n_; } while (0)
+    unsigned long long pt_ = __builtin_amdgcn_s_memtime();
+#else
+#define PT(k_) do {} while (0)
+#endif
     const int nb = S->nb;
     for (int i = 0; i < NB; ++i)
       if (i < nb) alpha0[i] = 0.0f;
@@ -1751,6 +1756,7 @@ struct Env {
       toiCount.set(s, 0);
       selSet(toi, s, (float)(1.0f));
     }
+    PT(0);
     for (int guard = 0; guard < 64 * (NP + 1); ++guard) {
       for (int k = 0; k < nc; ++k) {
         int s = wl.get(k);
@@ -1818,6 +1824,7 @@ struct Env {
           output.state = kTOISeparated;
           output.t = 1.0f;
         } else {
+          unsigned long long tq0 = profOn ? __builtin_amdgcn_s_memtime() : 0;
           // wall edge vs moving shape, everything in registers (blcd_toi_wall.h); the proxy width follows the shape so
           // that circles and boxes do not pay for 8-vertex select chains
           const Vec2 e0 = selGet(wallV0, pa_), e1 = selGet(wallV1, pa_);
@@ -1832,7 +1839,13 @@ struct Env {
             else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
             else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
           }
+#ifndef BLCD_PROF_TOI
           prof[4] += 1;
+#endif
+          if (profOn && (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) {  // once per wave-level execution
+            prof[6] += __builtin_amdgcn_s_memtime() - tq0;
+            prof[7] += 1;
+          }
         }
         float beta = output.t;
         if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
@@ -1840,6 +1853,7 @@ struct Env {
         selSet(toi, s, (float)(alpha));
         pflags.set(s, fl | PF_TOI);
       }
+      PT(1);
       // Phase 2: the minimum over the contact list (first minimum wins, as in the reference's `alpha < minAlpha`)
       int minSlot = -1;
       float minAlpha = 1.0f;
@@ -1855,6 +1869,7 @@ struct Env {
           minAlpha = alpha;
         }
       }
+      PT(4);
       if (minSlot < 0 || 1.0f - 10.0f * kEpsilon < minAlpha) break;
 
       const int wA = pairAOf(minSlot);      // wall (fixture A)
@@ -1882,7 +1897,9 @@ struct Env {
         continue;
       }
       wake(pB);
+#ifndef BLCD_PROF_TOI
       prof[5] += 1;
+#endif
       unsigned long long e0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
       // build the TOI island: contact list of the dynamic body, static others only
       uint32_t wallIsland = 1u << wA;
@@ -1942,7 +1959,10 @@ struct Env {
       }
       findNewContacts(false);
       if (profOn) prof[3] += __builtin_amdgcn_s_memtime() - e0_;
+      PT(5);
     }
+    PT(5);
+#undef PT
   }
 
   // b2World::Step
@@ -1967,8 +1987,10 @@ struct Env {
     if (!(skip & 4)) solveTOI(dt);
     if (profOn) {
       unsigned long long c3_ = __builtin_amdgcn_s_memtime();
+#ifndef BLCD_PROF_TOI
       prof[0] += c1_ - c0_;
       prof[1] += c2_ - c1_;
+#endif
       prof[2] += c3_ - c2_;
     }
     inv_dt0 = inv_dt;

@@ -31,4 +31,5 @@ for chunk in range(4):
     srt = np.sort(tot)[::-1]
     print(f'chunk {chunk}: kernel {ms:.3f} ms; waves {len(tot)}; sum/1024 {tot.sum()/1024:.3f} ms; max {tot.max():.3f}; p50 {np.median(tot):.3f}; '
           f'top-1024 mean {srt[:1024].mean():.3f}; first 8 waves {tot[:8].round(3).tolist()} last 4 {tot[-4:].round(3).tolist()}')
-    print('   mean kcycles collide/solve/toi/toi-event', (wt[:, 1:5].mean(0) / 1e3).round(1), ' max-wave', (wt[np.argmax(tot), 1:5] / 1e3).round(1))
+    print('   mean kcycles collide/solve/toi/toi-event', (wt[:, 1:5].mean(0) / 1e3).round(1), ' max-wave', (wt[np.argmax(tot), 1:5] / 1e3).round(1),
+          ' TOI routine: mean kcycles/wave', (wt[:, 7].mean() / 1e3).round(1), 'wave-level executions/wave', wt[:, 8].mean().round(1), 'lane-max calls', wt[:, 5].mean().round(1))
