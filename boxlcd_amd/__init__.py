@@ -10,6 +10,7 @@ from .world_env import WorldEnv, BatchedWorldEnv
 from .world_defs import WorldDef, Object, Robot
 from . import envs
 from .utils import AttrDict
+from . import goal  # BodyGoalEnv / CubeGoalEnv (research/wrappers) with the reward epilogue on device
 
 ENV_DG = AttrDict(WorldEnv.ENV_DG)
 env_map = {name: obj for name, obj in _inspect.getmembers(envs)

@@ -21,6 +21,9 @@ SYMBOLS = {
     'blcd_set_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'blcd_goal_set': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'blcd_goal_seed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'blcd_goal_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'blcd_get_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'blcd_render_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'blcd_get_poses': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -70,6 +73,12 @@ def _ptr(x):
   if hasattr(x, 'data_ptr'):
     return C.c_void_p(x.data_ptr())
   return x.ctypes.data_as(C.c_void_p)
+
+
+class GoalDesc(C.Structure):
+  """blcd_goal_desc (include/boxlcd.h)"""
+  _fields_ = [('mode', C.c_int32), ('diff_delt', C.c_int32), ('n_idx', C.c_int32), ('idxs', C.c_int32 * 96),
+              ('thresh', C.c_double), ('rew_scale', C.c_double)]
 
 
 class Handle:
@@ -135,6 +144,35 @@ class Handle:
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (T, self.n, self.n_act), actions.shape
     _check(self.lib.blcd_rollout(self._h, _ptr(actions), int(T), _ptr(lcd_out), _ptr(obs_out)))
+
+  def goal_set(self, mode, idxs_cols, thresh, rew_scale, diff_delt, goal_full_state, goal_lcd=None, env_idxs=None):
+    g = GoalDesc()
+    g.mode, g.diff_delt, g.n_idx = int(mode), int(bool(diff_delt)), len(idxs_cols)
+    for i, c in enumerate(idxs_cols):
+      g.idxs[i] = int(c)
+    g.thresh, g.rew_scale = float(thresh), float(rew_scale)
+    if not hasattr(goal_full_state, 'data_ptr'):
+      goal_full_state = np.ascontiguousarray(goal_full_state, dtype=np.float64)
+    if goal_lcd is not None and not hasattr(goal_lcd, 'data_ptr'):
+      goal_lcd = np.ascontiguousarray(goal_lcd, dtype=np.uint8)
+    n = self.n if env_idxs is None else len(env_idxs)
+    if env_idxs is not None:
+      env_idxs = np.ascontiguousarray(env_idxs, dtype=np.int32)
+    _check(self.lib.blcd_goal_set(self._h, C.byref(g), _ptr(env_idxs), n, _ptr(goal_full_state), _ptr(goal_lcd)))
+
+  def goal_seed(self, env_idxs=None):
+    n = self.n if env_idxs is None else len(env_idxs)
+    if env_idxs is not None:
+      env_idxs = np.ascontiguousarray(env_idxs, dtype=np.int32)
+    _check(self.lib.blcd_goal_seed(self._h, _ptr(env_idxs), n))
+
+  def goal_eval(self, rew=None, done=None, delta=None):
+    """-> (rew f64[N], done bool[N], delta f64[N]); pass torch tensors to keep the results on the device."""
+    rew = np.zeros(self.n, np.float64) if rew is None else rew
+    done = np.zeros(self.n, np.uint8) if done is None else done
+    delta = np.zeros(self.n, np.float64) if delta is None else delta
+    _check(self.lib.blcd_goal_eval(self._h, _ptr(rew), _ptr(done), _ptr(delta)))
+    return rew, done, delta
 
   def get_obs(self, dtype=np.float32, lcd=True):
     fs = None

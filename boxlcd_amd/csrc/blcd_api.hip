@@ -506,6 +506,12 @@ struct blcd_handle_s {
   int *binCounts = nullptr, *binOffsets = nullptr;
   int rebinEvery = 0;       // 0 = never; k = after every k-th env step
   int lanes = 64;           // environments per wave in step_kernel (BLCD_LANES)
+  // goal epilogue (blcd_goal_*): device-resident goals, previous deltas and scratch observation buffers
+  blcd_goal_desc goal{};
+  bool goalSet = false;
+  blcd_goal_desc* dGoal = nullptr;
+  double *goalFs = nullptr, *goalLast = nullptr, *goalObs = nullptr;
+  uint8_t *goalLcd = nullptr, *goalCurLcd = nullptr;
   int rolloutChunk = 20;    // env steps per fused rollout launch (BLCD_CHUNK; 0 = one launch per step + separate obs kernel)
   unsigned long long* waveTimes = nullptr;  // per-wave duration of the last step launch (diagnostic, BLCD_WAVETIMES=1)
   int stepsSinceRebin = 0;
@@ -666,6 +672,94 @@ static int launch_obs(blcd_handle h, ObsT* dObs, uint8_t* dLcd) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Goal epilogue kernels (research/wrappers/body_goal.py:58-88, cube_goal.py:64-86): one thread per environment.
+// np.mean over a contiguous float64 vector is numpy's pairwise sum divided by n (n < 8: sequential from 0.0; n <= 128:
+// eight interleaved accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail sequentially) - checked
+// against numpy on random vectors of 2..100 elements (tests/test_gpu_goal.py compares bit for bit).
+// ---------------------------------------------------------------------------------------------------------
+template <typename F>
+__device__ inline double np_pairwise_sum(F a, int n) {  // a(i) -> double, n <= 128
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += a(i);
+    return res;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a(j);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a(i + j);
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a(i);
+  return res;
+}
+template <typename F>
+__device__ inline double np_mean(F a, int n) {
+  return np_pairwise_sum(a, n) / (double)n;
+}
+
+__global__ void goal_scatter_kernel(const int* __restrict__ idxs, int n, int N, int nobs, int lcdBytes,
+                                    const double* __restrict__ fs, const uint8_t* __restrict__ lcd, double* __restrict__ goalFs,
+                                    uint8_t* __restrict__ goalLcd) {
+  int k = blockIdx.x;
+  if (k >= n) return;
+  int e = idxs ? idxs[k] : k;
+  if (e < 0 || e >= N) return;
+  for (int i = threadIdx.x; i < nobs; i += blockDim.x) goalFs[(size_t)e * nobs + i] = fs[(size_t)k * nobs + i];
+  if (lcd)
+    for (int i = threadIdx.x; i < lcdBytes; i += blockDim.x) goalLcd[(size_t)e * lcdBytes + i] = lcd[(size_t)k * lcdBytes + i];
+}
+
+// seedOnly: last_delta := delta for the listed envs; otherwise the full evaluation for every env
+__global__ void goal_eval_kernel(const blcd_goal_desc* __restrict__ G, int N, int nobs, int lcdBytes, const int* __restrict__ idxs,
+                                 int n, int seedOnly, const double* __restrict__ obs, const uint8_t* __restrict__ lcd,
+                                 const double* __restrict__ goalFs, const uint8_t* __restrict__ goalLcd,
+                                 double* __restrict__ last, double* __restrict__ rew, uint8_t* __restrict__ done,
+                                 double* __restrict__ deltaOut) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int e = idxs ? idxs[k] : k;
+  if (e < 0 || e >= N) return;
+  double delta, r;
+  bool d = false;
+  if (G->mode == 0) {
+    const double* o = obs + (size_t)e * nobs;
+    const double* g = goalFs + (size_t)e * nobs;
+    delta = np_mean([&](int i) { int c = G->idxs[i]; return fabs(g[c] - o[c]); }, G->n_idx);
+    if (seedOnly) {
+      last[e] = delta;
+      return;
+    }
+    if (G->diff_delt) r = -0.05 + 10.0 * (last[e] - delta);
+    else r = -delta;
+    if (delta < G->thresh) {
+      r += 1.0;
+      d = true;
+    }
+    last[e] = delta;
+  } else {
+    if (seedOnly) return;
+    const uint8_t* a = lcd + (size_t)e * lcdBytes;
+    const uint8_t* b = goalLcd + (size_t)e * lcdBytes;
+    int both = 0, zero = 0;
+    for (int i = 0; i < lcdBytes; ++i) {
+      zero += a[i] == 0;
+      both += (a[i] == 0) && (a[i] == b[i]);
+    }
+    delta = ((double)both / (double)lcdBytes) / ((double)zero / (double)lcdBytes);   // two np.mean of bool arrays
+    r = -1.0 + delta;
+    if (delta > G->thresh) {
+      r = 0.0;
+      d = true;
+    }
+  }
+  r = r * G->rew_scale;
+  if (rew) rew[e] = r;
+  if (done) done[e] = d ? 1 : 0;
+  if (deltaOut) deltaOut[e] = delta;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -740,6 +834,8 @@ int blcd_destroy(blcd_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (int k = 0; k < 4; ++k)
     if (h->stage[k]) (void)hipFree(h->stage[k]);
+  for (void* q : {(void*)h->dGoal, (void*)h->goalFs, (void*)h->goalLast, (void*)h->goalObs, (void*)h->goalLcd, (void*)h->goalCurLcd})
+    if (q) (void)hipFree(q);
   if (h->st) (void)hipFree(h->st);
   if (h->st2) (void)hipFree(h->st2);
   if (h->eid) (void)hipFree(h->eid);
@@ -887,6 +983,89 @@ int blcd_get_obs(blcd_handle h, void* full_state, int32_t dtype, uint8_t* lcd) {
   HIPCHK(hipStreamSynchronize(h->stream));
   if ((rc = out_done(h, 1, full_state, obsBytes, dObs))) return rc;
   if ((rc = out_done(h, 2, lcd, lcdBytes, dLcd))) return rc;
+  return BLCD_OK;
+}
+
+static int goal_buffers(blcd_handle h) {
+  const size_t nobs = h->hostScene.nobs, lcdBytes = (size_t)h->hostScene.lcdH * h->hostScene.lcdW;
+  if (!h->dGoal) {
+    HIPCHK(hipMalloc(&h->dGoal, sizeof(blcd_goal_desc)));
+    HIPCHK(hipMalloc(&h->goalFs, (size_t)h->N * nobs * sizeof(double)));
+    HIPCHK(hipMalloc(&h->goalObs, (size_t)h->N * nobs * sizeof(double)));
+    HIPCHK(hipMalloc(&h->goalLast, (size_t)h->N * sizeof(double)));
+    HIPCHK(hipMalloc(&h->goalLcd, (size_t)h->N * lcdBytes));
+    HIPCHK(hipMalloc(&h->goalCurLcd, (size_t)h->N * lcdBytes));
+    HIPCHK(hipMemsetAsync(h->goalFs, 0, (size_t)h->N * nobs * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->goalLast, 0, (size_t)h->N * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->goalLcd, 0, (size_t)h->N * lcdBytes, h->stream));
+  }
+  return BLCD_OK;
+}
+
+int blcd_goal_set(blcd_handle h, const blcd_goal_desc* g, const int32_t* idxs, int32_t n, const double* goal_full_state,
+                  const uint8_t* goal_lcd) {
+  if (!h || !g || !goal_full_state || n < 1 || n > h->N) return fail(BLCD_ERR_INVALID, "blcd_goal_set: bad arguments");
+  if (g->mode != 0 && g->mode != 1) return fail(BLCD_ERR_INVALID, "blcd_goal_set: mode must be 0 or 1");
+  if (g->mode == 0 && (g->n_idx < 1 || g->n_idx > BLCD_MAX_OBS))
+    return fail(BLCD_ERR_INVALID, "blcd_goal_set: n_idx out of range");
+  for (int i = 0; i < (g->mode == 0 ? g->n_idx : 0); ++i)
+    if (g->idxs[i] < 0 || g->idxs[i] >= h->hostScene.nobs) return fail(BLCD_ERR_INVALID, "blcd_goal_set: index outside full_state");
+  if (g->mode == 1 && !goal_lcd) return fail(BLCD_ERR_INVALID, "blcd_goal_set: mode 1 needs goal_lcd");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = goal_buffers(h))) return rc;
+  h->goal = *g;
+  HIPCHK(hipMemcpyAsync(h->dGoal, &h->goal, sizeof(blcd_goal_desc), hipMemcpyHostToDevice, h->stream));
+  const size_t nobs = h->hostScene.nobs, lcdBytes = (size_t)h->hostScene.lcdH * h->hostScene.lcdW;
+  const void *dIdx, *dFs, *dLcd;
+  if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
+  if ((rc = in_ptr(h, 1, goal_full_state, (size_t)n * nobs * sizeof(double), &dFs))) return rc;
+  if ((rc = in_ptr(h, 2, goal_lcd, (size_t)n * lcdBytes, &dLcd))) return rc;
+  hipLaunchKernelGGL(goal_scatter_kernel, dim3(n), dim3(64), 0, h->stream, (const int*)dIdx, n, h->N, (int)nobs, (int)lcdBytes,
+                     (const double*)dFs, (const uint8_t*)dLcd, h->goalFs, h->goalLcd);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->goalSet = true;
+  return BLCD_OK;
+}
+
+static int goal_launch(blcd_handle h, const int* dIdx, int n, int seedOnly, double* dRew, uint8_t* dDone, double* dDelta) {
+  int rc;
+  const bool needLcd = h->goal.mode == 1;
+  if ((rc = launch_obs<double>(h, needLcd ? nullptr : h->goalObs, needLcd ? h->goalCurLcd : nullptr))) return rc;
+  const int lcdBytes = h->hostScene.lcdH * h->hostScene.lcdW;
+  hipLaunchKernelGGL(goal_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->dGoal, h->N, h->hostScene.nobs, lcdBytes, dIdx,
+                     n, seedOnly, h->goalObs, h->goalCurLcd, h->goalFs, h->goalLcd, h->goalLast, dRew, dDone, dDelta);
+  HIPCHK(hipGetLastError());
+  return BLCD_OK;
+}
+
+int blcd_goal_seed(blcd_handle h, const int32_t* idxs, int32_t n) {
+  if (!h || !h->goalSet) return fail(BLCD_ERR_INVALID, "blcd_goal_seed: no goal installed (blcd_goal_set)");
+  if (!idxs) n = h->N;
+  if (n < 1 || n > h->N) return fail(BLCD_ERR_INVALID, "blcd_goal_seed: bad count");
+  HIPCHK(hipSetDevice(h->device));
+  const void* dIdx;
+  int rc;
+  if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
+  if ((rc = goal_launch(h, (const int*)dIdx, n, 1, nullptr, nullptr, nullptr))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLCD_OK;
+}
+
+int blcd_goal_eval(blcd_handle h, double* rew, uint8_t* done, double* delta) {
+  if (!h || !h->goalSet) return fail(BLCD_ERR_INVALID, "blcd_goal_eval: no goal installed (blcd_goal_set)");
+  HIPCHK(hipSetDevice(h->device));
+  void *dRew, *dDone, *dDelta;
+  int rc;
+  if ((rc = out_ptr(h, 0, rew, (size_t)h->N * sizeof(double), &dRew))) return rc;
+  if ((rc = out_ptr(h, 1, done, (size_t)h->N, &dDone))) return rc;
+  if ((rc = out_ptr(h, 2, delta, (size_t)h->N * sizeof(double), &dDelta))) return rc;
+  if ((rc = goal_launch(h, nullptr, h->N, 0, (double*)dRew, (uint8_t*)dDone, (double*)dDelta))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if ((rc = out_done(h, 0, rew, (size_t)h->N * sizeof(double), dRew))) return rc;
+  if ((rc = out_done(h, 1, done, (size_t)h->N, dDone))) return rc;
+  if ((rc = out_done(h, 2, delta, (size_t)h->N * sizeof(double), dDelta))) return rc;
   return BLCD_OK;
 }
 

@@ -133,6 +133,35 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
  * Either pointer may be NULL.  host|device. */
 int blcd_get_obs(blcd_handle h, void* full_state, int32_t dtype, uint8_t* lcd);
 
+/* Goal-conditioned reward / done epilogue, evaluated on device from the handle's current state.
+ * Replaces BodyGoalEnv.comp_rew_done (research/wrappers/body_goal.py:58-88) and CubeGoalEnv.comp_rew_done
+ * (research/wrappers/cube_goal.py:64-86), which the reference runs per process on host arrays:
+ *   mode 0 (state):  delta = mean_k |goal_full_state[idx_k] - full_state[idx_k]|   (float64, numpy's summation order)
+ *                    rew = diff_delt ? -0.05 + 10 (last_delta - delta) : -delta;  delta < thresh -> rew += 1, done
+ *   mode 1 (LCD):    similarity = mean(lcd == 0 & lcd == goal_lcd) / mean(lcd == 0);  rew = -1 + similarity;
+ *                    similarity > thresh -> rew = 0, done;  delta := similarity
+ *   finally rew *= rew_scale.  last_delta is the previous evaluation's delta (the reference's `last_obs`), kept per env. */
+typedef struct blcd_goal_desc {
+  int32_t mode;      /* 0 state distance, 1 LCD similarity */
+  int32_t diff_delt; /* mode 0 only */
+  int32_t n_idx;     /* mode 0: number of full_state columns compared (BodyGoalEnv: '.*(x|y):p' of proprio; CubeGoalEnv:
+                        'object.*(x|y):p') */
+  int32_t idxs[BLCD_MAX_OBS];
+  double thresh;     /* G.goal_thresh (body_goal.py:75), 0.05 (cube_goal.py:80) or 0.70 (body_goal.py:84) */
+  double rew_scale;  /* G.rew_scale (body_goal.py:98, cube_goal.py:59) */
+} blcd_goal_desc;
+
+/* Installs the reward definition and the goals of n environments (idxs NULL = environments 0..n-1).
+ * goal_full_state float64 [n][n_obs] (the goal observation's 'full_state'), goal_lcd uint8 [n][lcd_h][lcd_w] or NULL
+ * (needed for mode 1).  host|device. */
+int blcd_goal_set(blcd_handle h, const blcd_goal_desc* g, const int32_t* idxs, int32_t n, const double* goal_full_state,
+                  const uint8_t* goal_lcd);
+/* After a reset: last_delta := delta of the current state for the listed environments (idxs NULL = all). */
+int blcd_goal_seed(blcd_handle h, const int32_t* idxs, int32_t n);
+/* After a step: rew float64 [n_envs], done uint8 [n_envs] (the wrapper's own `_done`; the caller ORs the time limit),
+ * delta float64 [n_envs] (info['delta']); any may be NULL; updates last_delta.  host|device. */
+int blcd_goal_eval(blcd_handle h, double* rew, uint8_t* done, double* delta);
+
 /* Replaces the `env.reset(proprio=s)['lcd']` state->LCD use (research/nets/autoencoders/_base.py:69,76):
  * renders m pose sets without touching env state.  poses float32 [m][n_bodies][3] (x, y, angle of each body's
  * transform), shape_sel int32 [m][n_bodies] or NULL; lcd uint8 [m][lcd_h][lcd_w].  host|device. */

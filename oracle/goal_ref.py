@@ -1,0 +1,59 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  Nothing under boxlcd_amd/ may import this.
+
+numpy restatement of the goal wrappers' reward rules, one environment at a time, float64 like the reference:
+  body_comp_rew_done  <- research/wrappers/body_goal.py:58-88 (+ rew_scale, :98)
+  cube_comp_rew_done  <- research/wrappers/cube_goal.py:64-86 (+ rew_scale, :59)
+`obs` / `last_obs` are dicts with the keys the wrappers add ('goal:proprio', 'goal:lcd', 'goal:full_state')."""
+import re
+import numpy as np
+
+
+def filtlist(keys, phrase):  # research/utils.py:38
+  return [k for k in keys if re.match(phrase, k) is not None]
+
+
+def body_comp_rew_done(obs, last_obs, pobs_keys, state_rew, diff_delt, goal_thresh, rew_scale):
+  done = False
+  info = {}
+  if state_rew:
+    delta = np.abs(obs['goal:proprio'] - obs['proprio'])
+    keys = filtlist(pobs_keys, '.*(x|y):p')
+    idxs = [pobs_keys.index(x) for x in keys]
+    delta = delta[idxs].mean()
+    if diff_delt:
+      last_delta = np.abs(last_obs['goal:proprio'] - last_obs['proprio'])
+      last_delta = last_delta[idxs].mean()
+      rew = -0.05 + 10 * (last_delta - delta)
+    else:
+      rew = -delta
+    info['delta'] = delta
+    if delta < goal_thresh:
+      rew += 1.0
+      info['success'] = True
+      done = True
+  else:
+    similarity = (np.logical_and(obs['lcd'] == 0, obs['lcd'] == obs['goal:lcd']).mean() / (obs['lcd'] == 0).mean())
+    rew = -1 + similarity
+    info['delta'] = similarity
+    if similarity > 0.70:
+      rew = 0
+      info['success'] = True
+      done = True
+  return rew * rew_scale, done, info
+
+
+def cube_comp_rew_done(obs, last_obs, idxs, diff_delt, rew_scale):
+  info = {}
+  delta = np.abs(obs['goal:full_state'][..., idxs] - obs['full_state'][..., idxs]).mean()
+  if diff_delt:
+    last_delta = np.abs(obs['goal:full_state'][..., idxs] - last_obs['full_state'][..., idxs]).mean()
+    info['last_delta'] = last_delta
+    info['delta'] = delta
+    rew = -0.05 + 10 * (last_delta - delta)
+  else:
+    rew = -delta
+  done = False
+  if delta < 0.05:
+    done = True
+    rew += 1.0
+  return rew * rew_scale, done, info

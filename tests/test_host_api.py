@@ -149,3 +149,17 @@ def test_product_never_imports_oracle():
     if os.path.isfile(path) and path.endswith(('.py', '.h', '.hip', '.cpp')):
       txt = open(path, errors='ignore').read()
       assert 'b2o_' not in txt and 'pyb2o' not in txt and 'oracle/' not in txt.replace('the parity oracle', ''), path
+
+
+def test_goal_wrapper_column_selection():
+  """BodyGoalEnv compares every '(x|y):p' entry of proprio (body_goal.py:63-64), CubeGoalEnv the objects' (cube_goal.py:12-13);
+  host logic only (no GPU until reset())."""
+  from boxlcd_amd.goal import BodyGoalEnv, CubeGoalEnv
+  env = B.envs.UrchinCube()
+  body = BodyGoalEnv(env, {})
+  assert [env.obs_keys[c] for c in body._cols] == [k for k in env.pobs_keys if k.endswith(('x:p', 'y:p'))]
+  assert all(not env.obs_keys[c].startswith('object') for c in body._cols) and len(body._cols) == 8
+  cube = CubeGoalEnv(env, {})
+  assert cube.keys == ['object0:x:p', 'object0:y:p'] and [env.obs_keys[i] for i in cube.root_idxs] == ['urchin0:root:x:p', 'urchin0:root:y:p']
+  assert set(body.observation_space.spaces) >= {'goal:lcd', 'goal:proprio'}
+  assert cube.observation_space.spaces['goal:object'].shape == (2,)
