@@ -175,7 +175,8 @@ int blcd_get_poses(blcd_handle h, float* poses);
 int blcd_get_state(blcd_handle h, void* blob, size_t* size);
 int blcd_set_state(blcd_handle h, const void* blob, size_t size);
 
-/* Per-env fault flags raised on device since the last reset (0 = healthy): int32 [n_envs], host. */
+/* Per-env fault flags raised on device since the last reset (0 = healthy): int32 [n_envs], host.
+ * 1 non-finite state, 2 circle larger than the ellipse table, 4 more simultaneous contacts than the scene class holds. */
 int blcd_get_faults(blcd_handle h, int32_t* flags);
 
 /* Blocks until the handle's stream is idle; blcd_stream returns the hipStream_t so torch can order work against it. */
