@@ -217,32 +217,63 @@ __global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restr
 // has ~1.5x more waves than the chip has wave slots (occupancy 1), so heavy-first is longest-processing-time-first
 // scheduling: light waves backfill behind the heavy ones instead of the heavy ones starting last and forming the tail.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kBins = 8;
+// One-body scenes (Bounce, Dropbox) are additionally sorted by WHEN the body will next reach a wall: the expensive phases
+// (time of impact + TOI sub-step) run for a whole wave whenever one lane needs them, so a wave whose 64 environments hit a
+// wall at the same world step pays for them once instead of at almost every step.  The prediction integrates the free
+// flight with the solver's own semi-implicit Euler step (no damping, bounding circle); it only decides placement, never
+// results.  Keys: 0..31 = impact predicted in that many world steps, 32 = none within 32 steps, 33 = resting on a wall,
+// 40..46 = generic work classes (heaviest first), 47 = asleep.
+constexpr int kBins = 48;
+constexpr int kPredictSteps = 32;
 constexpr int kRebinBlock = 256;
 
-__device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot) {
+__device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode) {
   const int nb = S->nb, nj = S->nj, np = S->np;
   bool anyAwake = false;
   for (int i = 0; i < nb; ++i) anyAwake = anyAwake || st[(size_t)(i * kBodyFields + 12) * N + slot] != 0.0f;
   if (!anyAwake) return kBins - 1;
   const float* pp = st + (size_t)(nb * kBodyFields) * N + slot;
-  int nc = __float_as_int(pp[(size_t)(np * kPairFields + nj * kJointFields + 3) * N]);
-  if (nc == 0) return kBins - 2;
   int touching = 0;
   for (int s2 = 0; s2 < np; ++s2)
     if (__float_as_int(pp[(size_t)(s2 * kPairFields) * N]) & PF_TOUCHING) ++touching;
+  if (nb == 1 && nj == 0 && mode != 0) {
+    const float* bp = st + slot;
+    Vec2 p = V2(bp[0], bp[(size_t)1 * N]);
+    Vec2 v = V2(bp[(size_t)3 * N], bp[(size_t)4 * N]);
+    const int sel = __float_as_int(bp[(size_t)17 * N]);
+    const Shape& sh = S->shapes[S->bodies[0].var[sel].shape];
+    float R = sh.radius;
+    if (sh.type == kCircle) {
+      R += Length(sh.v[0]);
+    } else {
+      float m = 0.0f;
+      for (int i = 0; i < sh.count; ++i) m = Max(m, Length(sh.v[i] - S->bodies[0].var[sel].localCenter));
+      R += m;
+    }
+    const float slack = 0.02f, W = S->worldW, H = S->worldH, dt = S->dt;
+    if (touching > 0 && (mode == 2 || Dot(v, v) < 0.25f)) return kPredictSteps + 1;   // resting / rolling: the TOI early-out handles it
+    int n = 0;
+    for (; n < kPredictSteps; ++n) {
+      v += dt * S->gravity;
+      p += dt * v;
+      if (p.x - R < slack || p.x + R > W - slack || p.y - R < slack || p.y + R > H - slack) break;
+    }
+    return n;   // 0..31, or 32 = no wall within the horizon
+  }
+  int nc = __float_as_int(pp[(size_t)(np * kPairFields + nj * kJointFields + 3) * N]);
+  if (nc == 0) return kBins - 2;
   int c = 2 + touching;
-  return kBins - 1 - (c < kBins ? c : kBins - 1);
+  return kBins - 1 - (c < 8 ? c : 7);
 }
 
 __global__ __launch_bounds__(kRebinBlock) void rebin_hist_kernel(const DevScene* __restrict__ S, const float* __restrict__ st,
-                                                                 int N, uint8_t* __restrict__ keys, int* __restrict__ counts) {
+                                                                 int N, uint8_t* __restrict__ keys, int* __restrict__ counts, int mode) {
   __shared__ int h[kBins];
   if (threadIdx.x < kBins) h[threadIdx.x] = 0;
   __syncthreads();
   int slot = blockIdx.x * kRebinBlock + threadIdx.x;
   if (slot < N) {
-    int k = work_class(S, st, N, slot);
+    int k = work_class(S, st, N, slot, mode);
     keys[slot] = (uint8_t)k;
     atomicAdd(&h[k], 1);
   }
@@ -512,6 +543,7 @@ struct blcd_handle_s {
   blcd_goal_desc* dGoal = nullptr;
   double *goalFs = nullptr, *goalLast = nullptr, *goalObs = nullptr;
   uint8_t *goalLcd = nullptr, *goalCurLcd = nullptr;
+  int binMode = 1;          // work_class: 0 generic classes only, 1 impact-time sorting for one-body scenes (BLCD_BINMODE)
   int rolloutChunk = 20;    // env steps per fused rollout launch (BLCD_CHUNK; 0 = one launch per step + separate obs kernel)
   unsigned long long* waveTimes = nullptr;  // per-wave duration of the last step launch (diagnostic, BLCD_WAVETIMES=1)
   int stepsSinceRebin = 0;
@@ -643,7 +675,7 @@ static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* 
 // stable counting sort of slots by work class; swaps the state buffers
 static int launch_rebin(blcd_handle h) {
   int nBlocks = (h->N + kRebinBlock - 1) / kRebinBlock;
-  hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, h->stream, h->dScene, h->st, h->N, h->keys, h->binCounts);
+  hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, h->stream, h->dScene, h->st, h->N, h->keys, h->binCounts, h->binMode);
   hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->binCounts, h->binOffsets, nBlocks * kBins);
   hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, h->stream, h->st, h->st2, h->N, (int)h->words, h->keys,
                      h->binOffsets, h->eid, h->eid2, h->slotOf);
@@ -817,6 +849,7 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipStreamSynchronize(h->stream));
   // re-binning pays when environments sleep / fly freely (no joints keep them awake); BLCD_REBIN overrides (0 = off)
   h->rebinEvery = h->hostScene.nj == 0 ? 1 : 0;
+  if (const char* ev = getenv("BLCD_BINMODE")) h->binMode = atoi(ev);
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
   if (getenv("BLCD_WAVETIMES")) HIPCHK(hipMalloc((void**)&h->waveTimes, (size_t)n_envs * 9 * sizeof(unsigned long long)));
   if (const char* ev = getenv("BLCD_CHUNK")) h->rolloutChunk = atoi(ev);

@@ -33,3 +33,8 @@ for chunk in range(4):
           f'top-1024 mean {srt[:1024].mean():.3f}; first 8 waves {tot[:8].round(3).tolist()} last 4 {tot[-4:].round(3).tolist()}')
     print('   mean kcycles collide/solve/toi/toi-event', (wt[:, 1:5].mean(0) / 1e3).round(1), ' max-wave', (wt[np.argmax(tot), 1:5] / 1e3).round(1),
           ' TOI routine: mean kcycles/wave', (wt[:, 7].mean() / 1e3).round(1), 'wave-level executions/wave', wt[:, 8].mean().round(1), 'lane-max calls', wt[:, 5].mean().round(1))
+
+# wave time (last launch of the rollout) by position in the sorted order
+tot = wt[:, 0] * 10e-6
+nz = tot[:len(tot)]
+print('wave ms by position (every 64th):', nz[::64].round(3).tolist())
