@@ -215,6 +215,7 @@ struct Env {
   // of DevScene is a vector global load (hundreds of cycles at one wave per SIMD) in the middle of a dependent chain.
   Vec2 wallV0[4], wallV1[4];                 // the four wall edges (wave-uniform)
   float wallRad[4];
+  Vec2 wallFatLo[4], wallFatHi[4];           // their fat AABBs
   static constexpr bool kPairRegs = NP <= 4;   // ByteVec packs up to 4 entries into one register
   ByteVec<4> pairA_, pairB_;                 // pair table (proxy ids), one-body classes
   float crad[kCirc ? NB : 1];                // circles-only scenes: the bodies' shapes
@@ -248,6 +249,8 @@ struct Env {
       wallV0[k] = S->wallShape[k].v[0];
       wallV1[k] = S->wallShape[k].v[1];
       wallRad[k] = S->wallShape[k].radius;
+      wallFatLo[k] = S->wallFat[k].lo;
+      wallFatHi[k] = S->wallFat[k].hi;
     }
     pairA_.w = pairB_.w = 0;
     if (kPairRegs) {
@@ -465,7 +468,9 @@ struct Env {
   __device__ __forceinline__ AABB fatOf(int p) const {
     // value selects on purpose: `cond ? global : member` would become a select of POINTERS, which makes the member's
     // address escape as a flat pointer and keeps the whole Env object in scratch
-    const AABB w = S->wallFat[p < 4 ? p : 0];
+    AABB w;
+    w.lo = selGet(wallFatLo, p < 4 ? p : 0);
+    w.hi = selGet(wallFatHi, p < 4 ? p : 0);
     const AABB d = fat[p < 4 ? 0 : bi(p)];
     AABB r;
     r.lo.x = p < 4 ? w.lo.x : d.lo.x;
