@@ -628,9 +628,15 @@ static const Cfg kCfgs[] = {
 #undef X
 };
 static int pick_cfg(const DevScene& S) {
-  bool circlesOnly = true;  // every variant of every dynamic body is a circle
+  // circles-only classes: every variant of every dynamic body is a circle centred on the body origin (so is its centre of
+  // mass) and nothing is jointed - the conditions under which contact code never needs a body's rotation (Env::rotFor)
+  bool circlesOnly = S.nj == 0;
   for (int i = 0; i < S.nb; ++i)
-    for (int k = 0; k < S.bodies[i].nChoices; ++k) circlesOnly = circlesOnly && S.shapes[S.bodies[i].var[k].shape].type == kCircle;
+    for (int k = 0; k < S.bodies[i].nChoices; ++k) {
+      const Shape& sh = S.shapes[S.bodies[i].var[k].shape];
+      const Vec2 lc = S.bodies[i].var[k].localCenter;
+      circlesOnly = circlesOnly && sh.type == kCircle && sh.v[0].x == 0.0f && sh.v[0].y == 0.0f && lc.x == 0.0f && lc.y == 0.0f;
+    }
   for (size_t i = 0; i < sizeof(kCfgs) / sizeof(kCfgs[0]); ++i)
     if (S.nb <= kCfgs[i].nb && S.nj <= kCfgs[i].nj && S.np <= kCfgs[i].np && (kCfgs[i].sh == 0 || circlesOnly)) return (int)i;
   return -1;

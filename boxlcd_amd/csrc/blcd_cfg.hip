@@ -2,6 +2,9 @@
 // (compile with -DBLCD_NB=<max bodies> -DBLCD_NJ=<max joints> -DBLCD_NP=<max pair slots> -DBLCD_SH=<shape set>; see
 // blcd_cfg_launch.h).
 #include <hip/hip_runtime.h>
+#if !defined(BLCD_SH) || BLCD_SH == 0
+#define BLCD_SINCOS_INLINE 1   // general classes call sincosf in their hot loops (position solver, TOI): keep it inlined there
+#endif
 #include "blcd_emit.h"
 #include "blcd_cfg_launch.h"
 

@@ -47,7 +47,12 @@ __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn 
       body(i, &p, &a, &sel);
       Transform xf;
       xf.p = p;
-      xf.q.Set(a);
+      if (CIRC) {  // a circle's frame does not depend on its rotation
+        xf.q.s = 0.0f;
+        xf.q.c = 1.0f;
+      } else {
+        xf.q.Set(a);
+      }
       ok = r.template drawBody<CIRC>(&S->shapes[S->bodies[i].var[sel].shape], xf, (double)S->worldW, (double)S->lcdW) && ok;
     }
     r.write(lcdRow);

@@ -75,7 +75,16 @@ BLCD_HD static inline void sincos_poly(double x, double x2, float* sinv, float* 
   *cosv = (float)(c + x6 * c2_);
 }
 
-BLCD_HD static inline void blcd_sincosf(float y, float* sinp, float* cosp) {
+// Out of line unless BLCD_SINCOS_INLINE: the circles-only step kernels need sincosf only on cold paths, and 58 inlined
+// copies (~250 instructions each) were a third of a kernel that is already far larger than the instruction cache
+// (measured: Bounce +6 %).  Kernels that call it in hot loops (general classes: position solver, TOI of polygons) define
+// BLCD_SINCOS_INLINE - out of line costs them 5-12 %.
+#if defined(BLCD_SINCOS_INLINE)
+#define BLCD_SINCOS_ATTR inline
+#else
+#define BLCD_SINCOS_ATTR __attribute__((noinline))
+#endif
+BLCD_HD static BLCD_SINCOS_ATTR void blcd_sincosf(float y, float* sinp, float* cosp) {
   double x = y;
   if (abstop12(y) < 0x3f4u) {          // |y| < 0x1.921FB6p-1f's top-12 class
     if (abstop12(y) < 0x398u) {        // |y| < 2^-12

@@ -73,7 +73,8 @@ struct CacheR {
   int iA0, iA1, iA2, iB0, iB1, iB2;
 };
 
-template <int MAXV>
+// DEAD: the caller guarantees a one-vertex proxy at the body origin with the centre of mass there (see xfAt)
+template <int MAXV, bool DEAD = false>
 struct TOIWall {
   EdgeR A;
   ProxyR<MAXV> B;
@@ -228,7 +229,7 @@ struct TOIWall {
     if (t == mkB) return mxB;
     if (t == mkC) return mxC;
     Transform xf;
-    if (MAXV == 1 && qDead) {
+    if (DEAD || (MAXV == 1 && qDead)) {
       // circle whose centre is the body origin (and the centre of mass): every use of q below multiplies the zero vector
       // (vertex (0,0), localCenter (0,0); the support of a 1-vertex proxy is always 0), so sincosf is skipped.  Values are
       // unchanged; only the sign of an exact zero could differ.

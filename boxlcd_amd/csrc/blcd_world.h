@@ -434,7 +434,15 @@ struct Env {
   // unchanged, only the sign of an exact zero could differ.  This includes the body's stored rotation q[i]: it is not part
   // of the persistent state (observations and the raster recompute sin/cos from the angle) and is read by contact code only.
   uint32_t deadQ;
-  __device__ __forceinline__ Rot rotFor(int p, float angle) const { return rotDead(deadQ, p, angle); }
+  __device__ __forceinline__ Rot rotFor(int p, float angle) const {
+    if (kCirc) {  // circles-only classes are picked only for origin-centred circles without joints: every bit is set
+      Rot r;
+      r.s = 0.0f;
+      r.c = 1.0f;
+      return r;
+    }
+    return rotDead(deadQ, p, angle);
+  }
   __device__ __forceinline__ int pairAOf(int s) const { return kPairRegs ? pairA_.get(s) : S->pairs[s].a; }
   __device__ __forceinline__ int pairBOf(int s) const { return kPairRegs ? pairB_.get(s) : S->pairs[s].b; }
   __device__ __forceinline__ Shape wallShapeReg(int p) const {  // only type/radius/count/v[0..1] are meaningful
@@ -1703,7 +1711,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   template <int MAXV>
   static __device__ __forceinline__ void toiWallRun(TOIOutput* out, Vec2 e0, Vec2 e1, float er, const Shape* shB, const Sweep& sw) {
-    TOIWall<MAXV> tw;
+    TOIWall<MAXV, kCirc> tw;
     tw.A.a0 = e0;
     tw.A.a1 = e1;
     tw.A.radius = er;
