@@ -16,6 +16,8 @@ __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn 
                                          uint8_t* __restrict__ lcdRow) {
   bool ok = true;
   if (obsRow) {
+    int cachedKey = -1;   // (body, angle source) whose float64 sin/cos are in cs / cc: the cos and sin entries of a body are
+    double cs = 0.0, cc = 1.0;   // adjacent in the obs table, so one sincos() serves both
     for (int i = 0; i < S->nobs; ++i) {
       const DevObs od = S->obs[i];
       Vec2 p;
@@ -26,12 +28,17 @@ __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn 
       if (od.kind == 0) val = (double)p.x;
       else if (od.kind == 1) val = (double)p.y;
       else {
-        if (od.kind >= 4) {  // transform.angle = atan2f(q.s, q.c)
-          Rot q;
-          q.Set(a);
-          a = atan2f(q.s, q.c);
+        const int key = od.body * 2 + (od.kind >= 4 ? 1 : 0);
+        if (key != cachedKey) {
+          if (od.kind >= 4) {  // transform.angle = atan2f(q.s, q.c)
+            Rot q;
+            q.Set(a);
+            a = atan2f(q.s, q.c);
+          }
+          sincos((double)a, &cs, &cc);
+          cachedKey = key;
         }
-        val = (od.kind == 2 || od.kind == 4) ? cos((double)a) : sin((double)a);
+        val = (od.kind == 2 || od.kind == 4) ? cc : cs;
       }
       double lo = (double)od.lo, hi = (double)od.hi;
       obsRow[i] = (ObsT)(((val - lo) / (hi - lo) * 2.0) + -1.0);

@@ -175,9 +175,11 @@ struct Raster {
       RowT m = rows[H - 1 - r];
       uint8_t* o = out + r * W;
       for (int x0 = 0; x0 < W; x0 += 8) {  // W is a multiple of 8 for every boxLCD env (16, 24, 32, 64)
-        uint32_t lo = 0, hi = 0;
-        for (int k = 0; k < 4; ++k) lo |= (uint32_t)(((m >> (x0 + k)) & 1) ? 0u : 1u) << (8 * k);
-        for (int k = 0; k < 4; ++k) hi |= (uint32_t)(((m >> (x0 + 4 + k)) & 1) ? 0u : 1u) << (8 * k);
+        // 4 mask bits -> 4 bytes: x * (1 + 2^7 + 2^14 + 2^21) puts bit j at position 8j (no carries: the four shifted copies
+        // of a 4-bit value do not overlap); body bit set -> pixel 0, background -> 1
+        const uint32_t b8 = (uint32_t)(m >> x0) & 0xffu;
+        const uint32_t lo = (((b8 & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+        const uint32_t hi = (((b8 >> 4) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
         *reinterpret_cast<uint2*>(o + x0) = make_uint2(lo, hi);
       }
     }
