@@ -81,7 +81,9 @@ def run_robot(name, N=200000, gens=12, half=0.004, wide_from=None):
   rng = np.random.RandomState(0)
   k = len(u0)
   U = u0 + rng.uniform(-1, 1, (N, k)) * half * free
-  if wide_from is not None:      # draws >= wide_from (the object's) start uniform over their whole range
+  if wide_from is not None:      # draws >= wide_from (the object's) start uniform over the whole normalised range: the recording's
+    lo[wide_from:] = -0.95       # sampling ranges for objects differ from today's code (LuxoCube's cube starts on the lamp)
+    hi[wide_from:] = 0.95
     U[:, wide_from:] = lo[wide_from:] + rng.uniform(0, 1, (N, k - wide_from)) * (hi - lo)[wide_from:]
   U[0] = u0
   best = (10**9, None, None)
