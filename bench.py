@@ -67,7 +67,10 @@ def main():
   from boxlcd_amd import dist as bdist
   from boxlcd_amd._lib import Handle
 
-  rank, world, local = bdist.init_from_env()
+  # BENCH_BACKEND=gloo BENCH_DEVICE=0: rehearse the N>1 path on a box with fewer GPUs than ranks (never used by the driver)
+  rank, world, local = bdist.init_from_env(os.environ.get('BENCH_BACKEND'))
+  if 'BENCH_DEVICE' in os.environ:
+    local = int(os.environ['BENCH_DEVICE'])
   if world != args.gpus:
     if rank == 0:
       print(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
