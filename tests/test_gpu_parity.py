@@ -164,3 +164,29 @@ def test_partial_reset_and_set_poses():
   for e, o in zip(idxs, oras):
     assert (lcd[e] == o.render()).all() and (d[e][:, :6] == o.dump()[0][:, :6]).all()
   h.close()
+
+
+@pytest.mark.parametrize('name,n', [('UrchinBall', 100), ('Bounce', 1000), ('Object2', 77)])
+def test_fused_rollout_ragged_batch_matches_oracle(name, n):
+  """blcd_rollout (fused chunks, re-binning between chunks, per-step LCD/obs rows) on batch sizes that are not multiples of the
+  wave width: final state + every per-step LCD frame of a few envs against the oracle stepped one env-step at a time."""
+  T = 45
+  env = B.BatchedWorldEnv(name, n, seed=9)
+  poses, sel = env.sample_initial(n)
+  acts = env.sample_actions(T)
+  h = Handle(env.scene.desc, n, 0)
+  h.reset(None, poses, sel)
+  lcd = np.zeros((T, n, env.scene.desc.lcd_h, env.scene.desc.lcd_w), np.uint8)
+  obs = np.zeros((T, n, env.scene.desc.n_obs), np.float32)
+  h.rollout(acts, T, lcd, obs)
+  state = h.debug_dump()[0]
+  _, oobs, olcd, ost = pyb2o.rollout(env.scene.desc, poses, sel, acts, T, threads=8)
+  assert (state == ost).all() and (lcd[-1] == olcd).all() and np.abs(obs[-1] - oobs).max() < 1e-6
+  for e in (0, n // 2, n - 1):           # per-step rows of three envs, including the last (ragged) lane
+    o = pyb2o.OracleEnv(env.scene.desc)
+    o.reset(poses[e], sel[e])
+    for t in range(T):
+      o.step(acts[t, e])
+      assert (lcd[t, e] == o.render()).all() and np.abs(obs[t, e] - o.obs()).max() < 1e-6, (e, t)
+  assert not h.faults().any()
+  h.close()
