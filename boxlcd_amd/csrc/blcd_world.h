@@ -1363,7 +1363,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // register-resident island solve (blcd_island_reg.h) for multi-body scenes: islands with <= kRegC contacts
   // ------------------------------------------------------------------------------------------------
-  static constexpr bool kUseReg = (NB > 1) && (NB <= 8) && (NJ <= 4);
+  static constexpr bool kUseReg = (NB > 1) && (NB <= 5) && (NJ <= 4);   // beyond 5 bodies the staged island no longer fits the register file (991 spills at NB = 7)
   static constexpr int kRegC = 4;
   __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
     const int nb = S->nb;
