@@ -6,7 +6,7 @@ REPO=$PWD
 TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
-BENCH="python3 $REPO/bench.py --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --no-cpu-baseline $BENCH_ARGS"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o stats --output-format csv -- $BENCH > $REPO/gpurun_out/${TAG}_stats_run.log 2>&1 || { tail -5 $REPO/gpurun_out/${TAG}_stats_run.log; exit 1; }
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $REPO/gpurun_out/${TAG}_kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES"; do
