@@ -466,36 +466,24 @@ struct RegIsland {
       Vec3 Cdot = Vec3{Cdot1.x, Cdot1.y, Cdot2};
       Vec3 impulse = -Mx.Solve33(Cdot);
       Vec3 acc = J.imp;
-      if (limitState == 3) {
-        acc += impulse;
-      } else if (limitState == 1) {
-        float newImpulse = acc.z + impulse.z;
-        if (newImpulse < 0.0f) {
-          Vec2 rhs = -Cdot1 + acc.z * V2(Mx.ez.x, Mx.ez.y);
-          Vec2 reduced = Mx.Solve22(rhs);
-          impulse.x = reduced.x;
-          impulse.y = reduced.y;
-          impulse.z = -acc.z;
-          acc.x += reduced.x;
-          acc.y += reduced.y;
-          acc.z = 0.0f;
-        } else {
-          acc += impulse;
-        }
-      } else if (limitState == 2) {
-        float newImpulse = acc.z + impulse.z;
-        if (newImpulse > 0.0f) {
-          Vec2 rhs = -Cdot1 + acc.z * V2(Mx.ez.x, Mx.ez.y);
-          Vec2 reduced = Mx.Solve22(rhs);
-          impulse.x = reduced.x;
-          impulse.y = reduced.y;
-          impulse.z = -acc.z;
-          acc.x += reduced.x;
-          acc.y += reduced.y;
-          acc.z = 0.0f;
-        } else {
-          acc += impulse;
-        }
+      {
+        // The limit cases of b2RevoluteJoint::SolveVelocityConstraints, predicated: lanes of a wave sit in different limit
+        // states, so the branchy form ran up to five short paths one after the other.  Both candidate results are formed
+        // with the reference's expressions and one is selected per lane (equal limits: always the plain accumulation).
+        const float newImpulse = acc.z + impulse.z;
+        const bool clampCase = (limitState == 1 && newImpulse < 0.0f) || (limitState == 2 && newImpulse > 0.0f);
+        const Vec2 rhs = -Cdot1 + acc.z * V2(Mx.ez.x, Mx.ez.y);
+        const Vec2 reduced = Mx.Solve22(rhs);
+        Vec3 accPlain = acc;
+        accPlain += impulse;
+        const Vec3 impClamp = Vec3{reduced.x, reduced.y, -acc.z};
+        const Vec3 accClamp = Vec3{acc.x + reduced.x, acc.y + reduced.y, 0.0f};
+        impulse.x = clampCase ? impClamp.x : impulse.x;
+        impulse.y = clampCase ? impClamp.y : impulse.y;
+        impulse.z = clampCase ? impClamp.z : impulse.z;
+        acc.x = clampCase ? accClamp.x : accPlain.x;
+        acc.y = clampCase ? accClamp.y : accPlain.y;
+        acc.z = clampCase ? accClamp.z : accPlain.z;
       }
       changed = changed || (impulse.x != 0.0f) || (impulse.y != 0.0f) || (impulse.z != 0.0f) || (acc.x != J.imp.x) ||
                 (acc.y != J.imp.y) || (acc.z != J.imp.z);
