@@ -50,6 +50,18 @@ def cpu_baseline(env_name, T, target_s=12.0):
           'sample': f'{n} {env_name} envs x {T} env-steps from reset, obs+LCD every step, {cores} threads, {sec:.1f} s'}
 
 
+def parity_sample(desc, poses, sel, acts, T, gpu_state, gpu_lcd, idx, cores):
+  """BASELINE.json's second metric ("LCD frame bit-match %", positions within 1e-4): the oracle as checker on a sample of the
+  environments the timed rollout just advanced (same start poses, same action tape)."""
+  import numpy as np
+  from oracle import pyb2o
+  a = None if acts is None else acts[:, idx]
+  _, _, olcd, ost = pyb2o.rollout(desc, poses[idx], sel[idx], a, T, threads=cores)
+  return {'envs_compared': int(len(idx)), 'env_steps': int(T),
+          'lcd_frame_bit_match_pct': 100.0 * float((gpu_lcd[idx] == olcd).reshape(len(idx), -1).all(1).mean()),
+          'max_abs_pose_diff': float(np.abs(gpu_state[idx][:, :, :3] - ost[:, :, :3]).max())}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -145,6 +157,9 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args.env, T)
+      idx = np.random.RandomState(0).choice(N, min(N, 1024), replace=False)
+      out['parity'] = parity_sample(d, poses_np, sel_np, acts.cpu().numpy(), T, h.debug_dump()[0], lcd[-1].cpu().numpy(), idx,
+                                    out['cpu_baseline']['cores'])
     print(json.dumps(out))
   h.close()
   if world > 1:
