@@ -100,7 +100,7 @@ struct TOIWall {
     count = c.count;
     if (count > 0) { makeVertex(v1, c.iA0, c.iB0, xfB); v1.a = 0.0f; }
     if (count > 1) { makeVertex(v2, c.iA1, c.iB1, xfB); v2.a = 0.0f; }
-    if (count > 2) { makeVertex(v3, c.iA2, c.iB2, xfB); v3.a = 0.0f; }
+    if (MAXV > 1 && count > 2) { makeVertex(v3, c.iA2, c.iB2, xfB); v3.a = 0.0f; }
     if (count > 1) {
       float metric1 = c.metric;
       float metric2 = metric();
@@ -173,9 +173,10 @@ struct TOIWall {
     while (iter < k_maxIters) {
       int saveCount = count;
       int sA0 = v1.indexA, sB0 = v1.indexB, sA1 = v2.indexA, sB1 = v2.indexB, sA2 = v3.indexA, sB2 = v3.indexB;
+      // a one-vertex proxy against a two-vertex edge can never hold three distinct simplex vertices
       if (count == 2) solve2();
-      else if (count == 3) solve3();
-      if (count == 3) break;
+      else if (MAXV > 1 && count == 3) solve3();
+      if (MAXV > 1 && count == 3) break;
       Vec2 d;
       if (count == 1) {
         d = -v1.w;
