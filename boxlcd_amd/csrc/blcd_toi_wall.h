@@ -93,7 +93,7 @@ struct TOIWall {
     v.indexA = ia;
     v.indexB = ib;
     v.wA = A.vertex(ia);             // identity transform
-    v.wB = Mul(xfB, B.vertex(ib));
+    v.wB = DEAD ? xfB.p : Mul(xfB, B.vertex(ib));   // DEAD: the vertex is the body origin (q*0 + p == p)
     v.w = v.wB - v.wA;
   }
   __device__ __forceinline__ void readCache(const CacheR& c, const Transform& xfB) {
@@ -226,6 +226,13 @@ struct TOIWall {
     mkA = mkB = mkC = __builtin_nanf("");
   }
   __device__ __forceinline__ Transform xfAt(float t) {
+    if (DEAD) {  // two multiply-adds per coordinate: cheaper than consulting the memo
+      Transform xf;
+      xf.p = (1.0f - t) * sweepB.c0 + t * sweepB.c;
+      xf.q.s = 0.0f;
+      xf.q.c = 1.0f;
+      return xf;
+    }
     if (t == mkA) return mxA;
     if (t == mkB) return mxB;
     if (t == mkC) return mxC;
@@ -265,7 +272,7 @@ struct TOIWall {
       Vec2 pointB = Mul(xfB, B.vertex(cache.iB0));
       sfAxis = pointB - pointA;
       Normalize(sfAxis);
-    } else if (cache.iA0 == cache.iA1) {
+    } else if (MAXV > 1 && cache.iA0 == cache.iA1) {   // two distinct points on B: impossible for a one-vertex proxy
       sfType = 2;
       Vec2 localPointB1 = B.vertex(cache.iB0);
       Vec2 localPointB2 = B.vertex(cache.iB1);
@@ -297,14 +304,14 @@ struct TOIWall {
       *indexA = A.support(sfAxis);
       *indexB = B.support(MulT(xfB.q, -sfAxis));
       Vec2 pointA = A.vertex(*indexA);
-      Vec2 pointB = Mul(xfB, B.vertex(*indexB));
+      Vec2 pointB = DEAD ? xfB.p : Mul(xfB, B.vertex(*indexB));
       return Dot(pointB - pointA, sfAxis);
-    } else if (sfType == 1) {
+    } else if (MAXV == 1 || sfType == 1) {
       Vec2 normal = sfAxis;
       Vec2 pointA = sfLocalPoint;
       *indexA = -1;
       *indexB = B.support(MulT(xfB.q, -normal));
-      Vec2 pointB = Mul(xfB, B.vertex(*indexB));
+      Vec2 pointB = DEAD ? xfB.p : Mul(xfB, B.vertex(*indexB));
       return Dot(pointB - pointA, normal);
     } else {
       Vec2 normal = Mul(xfB.q, sfAxis);
@@ -319,12 +326,12 @@ struct TOIWall {
     Transform xfB = xfAt(t);
     if (sfType == 0) {
       Vec2 pointA = A.vertex(indexA);
-      Vec2 pointB = Mul(xfB, B.vertex(indexB));
+      Vec2 pointB = DEAD ? xfB.p : Mul(xfB, B.vertex(indexB));
       return Dot(pointB - pointA, sfAxis);
-    } else if (sfType == 1) {
+    } else if (MAXV == 1 || sfType == 1) {
       Vec2 normal = sfAxis;
       Vec2 pointA = sfLocalPoint;
-      Vec2 pointB = Mul(xfB, B.vertex(indexB));
+      Vec2 pointB = DEAD ? xfB.p : Mul(xfB, B.vertex(indexB));
       return Dot(pointB - pointA, normal);
     } else {
       Vec2 normal = Mul(xfB.q, sfAxis);
