@@ -443,8 +443,16 @@ struct Env {
     }
     return rotDead(deadQ, p, angle);
   }
-  __device__ __forceinline__ int pairAOf(int s) const { return kPairRegs ? pairA_.get(s) : S->pairs[s].a; }
-  __device__ __forceinline__ int pairBOf(int s) const { return kPairRegs ? pairB_.get(s) : S->pairs[s].b; }
+  // One-body classes: every pair slot is (wall, the body) - static-static pairs do not exist - so B is proxy 4 and A < 4.
+  __device__ __forceinline__ int pairAOf(int s) const {
+    int a_ = kPairRegs ? pairA_.get(s) : S->pairs[s].a;
+    if constexpr (NB == 1) a_ &= 3;
+    return a_;
+  }
+  __device__ __forceinline__ int pairBOf(int s) const {
+    if constexpr (NB == 1) return 4;
+    return kPairRegs ? pairB_.get(s) : S->pairs[s].b;
+  }
   __device__ __forceinline__ Shape wallShapeReg(int p) const {  // only type/radius/count/v[0..1] are meaningful
     Shape w{};
     w.type = kEdge;
