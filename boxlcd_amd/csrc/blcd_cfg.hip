@@ -24,6 +24,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut) {
+  __shared__ uint32_t ldsRows[64 * 17];   // LCD row masks of the wave's 64 environments (stride 17: conflict-free)
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
   // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
@@ -49,8 +50,32 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
           *a = env.a[bi];
           *sel = env.sel[bi];
         };
-        bool ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr,
-                                                lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr);
+        bool ok;
+        if (lcdOut && S->lcdW == 16 && __ballot(1) == ~0ull) {   // full waves only: a frame needs all 64 lanes to write it
+          // 16x16 frames: 256 B = one dword per lane.  Writing each lane's own frame row by row makes every store touch 64
+          // different cache lines; instead the lanes park their 16 row masks in LDS and the wave writes one whole frame per
+          // store instruction (fully coalesced), frame k being the environment held by lane k.
+          uint32_t rows[16];
+          ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
+          const int lane = (int)threadIdx.x;
+#pragma unroll
+          for (int y = 0; y < 16; ++y) ldsRows[lane * 17 + y] = rows[y];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          uint8_t* frames = lcdOut + (size_t)t * N * lcdRow;
+          const int row = lane >> 2, x0 = (lane & 3) * 4;   // this lane's 4 pixels of any frame
+          for (int k = 0; k < 64; ++k) {
+            const int ek = __builtin_amdgcn_readlane(e, k);
+            const uint32_t m = ldsRows[k * 17 + row];
+            const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+            *reinterpret_cast<uint32_t*>(frames + (size_t)ek * 256 + 4 * lane) = px;
+          }
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr,
+                                                      lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr);
+        }
         if (!ok) env.fault |= FAULT_ELLIPSE;
       }
     }

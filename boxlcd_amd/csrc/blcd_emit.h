@@ -13,7 +13,7 @@ constexpr int kBlock = 64;  // one wave per workgroup: N/64 workgroups spread ov
 // yields transform position, body angle and shape choice of body i.  Shared by obs_kernel and the fused rollout path.
 template <int H, typename RowT, typename ObsT, bool CIRC = false, typename BodyFn>
 __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn body, ObsT* __restrict__ obsRow,
-                                         uint8_t* __restrict__ lcdRow) {
+                                         uint8_t* __restrict__ lcdRow, RowT* __restrict__ rowsOut = nullptr) {
   bool ok = true;
   if (obsRow) {
     int cachedKey = -1;   // (body, angle source) whose float64 sin/cos are in cs / cc: the cos and sin entries of a body are
@@ -44,7 +44,7 @@ __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn 
       obsRow[i] = (ObsT)(((val - lo) / (hi - lo) * 2.0) + -1.0);
     }
   }
-  if (lcdRow) {
+  if (lcdRow || rowsOut) {
     Raster<H, RowT> r;
     r.clear(S->lcdW, S->rasterVariant);
     for (int i = 0; i < S->nb; ++i) {
@@ -62,7 +62,12 @@ __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn 
       }
       ok = r.template drawBody<CIRC>(&S->shapes[S->bodies[i].var[sel].shape], xf, (double)S->worldW, (double)S->lcdW) && ok;
     }
-    r.write(lcdRow);
+    if (rowsOut) {   // the caller writes the frame itself (wave-coalesced, see step_kernel): rows in output order
+#pragma unroll
+      for (int y = 0; y < H; ++y) rowsOut[y] = r.rows[H - 1 - y];
+    } else {
+      r.write(lcdRow);
+    }
   }
   return ok;
 }
