@@ -290,14 +290,16 @@ __global__ void rebin_scan_kernel(const int* __restrict__ counts, int* __restric
   for (int i = lo; i < hi; ++i) sum += counts[i];
   part[tid] = sum;
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int i = 0; i < 1024; ++i) {
-      int t = part[i];
-      part[i] = acc;
-      acc += t;
-    }
+  // exclusive scan of the 1024 partial sums (Hillis-Steele in LDS: 10 steps instead of a 1024-long serial loop)
+  for (int d = 1; d < 1024; d <<= 1) {
+    int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
   }
+  int excl = part[tid] - sum;
+  __syncthreads();
+  part[tid] = excl;
   __syncthreads();
   int acc = part[tid];
   for (int i = lo; i < hi; ++i) {
