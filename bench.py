@@ -136,7 +136,7 @@ def main():
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     traffic = None   # HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes of this same command
     try:
-      prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_final3_bounce100k_pmc.json')))
+      prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_final4_bounce100k_pmc.json')))
       if args.env == 'Bounce' and N == 100000 and T == 200:
         k = [x for x in prof if 'step_kernel' in x][0]
         traffic = (prof[k]['FETCH_SIZE']['mean'] + prof[k]['WRITE_SIZE']['mean']) * 1024.0
@@ -151,7 +151,7 @@ def main():
                    'parallelism': f'env-sharded x{world}', 'raster_variant': 'legacy', 'faulted_envs': faults,
                    'awake_fraction_at_end': awake_frac},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': 'profiles/r01_final3_bounce100k_pmc.json (FETCH_SIZE + WRITE_SIZE, KB -> B, per launch)', 'kernel': 'step_kernel',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': 'profiles/r01_final4_bounce100k_pmc.json (FETCH_SIZE + WRITE_SIZE, KB -> B, per launch)', 'kernel': 'step_kernel',
                      'avg_launch_ms': avg_launch_s * 1e3, 'env_steps_per_env_per_launch': steps_per_launch, 'alg_bytes_per_env_step': ALG_BYTES.get(args.env, 0),
                      'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'},
     }
