@@ -216,6 +216,7 @@ struct Env {
   Vec2 wallV0[4], wallV1[4];                 // the four wall edges (wave-uniform)
   float wallRad[4];
   Vec2 wallFatLo[4], wallFatHi[4];           // their fat AABBs
+  Vec2 wallNrm[4], wallTan[4];               // (edge x 1)/|edge| and edge/|edge|^2: for the conservative TOI early-out only
   static constexpr bool kPairRegs = NP <= 4;   // ByteVec packs up to 4 entries into one register
   ByteVec<4> pairA_, pairB_;                 // pair table (proxy ids), one-body classes
   float crad[kCirc ? NB : 1];                // circles-only scenes: the bodies' shapes
@@ -249,6 +250,13 @@ struct Env {
       wallV0[k] = S->wallShape[k].v[0];
       wallV1[k] = S->wallShape[k].v[1];
       wallRad[k] = S->wallShape[k].radius;
+      {
+        const Vec2 ed = wallV1[k] - wallV0[k];
+        const float len2 = Dot(ed, ed);
+        const float inv = 1.0f / sqrtf(len2);
+        wallNrm[k] = V2(ed.y * inv, -ed.x * inv);   // Cross(ed, r) * inv == Dot(r, wallNrm)
+        wallTan[k] = V2(ed.x / len2, ed.y / len2);
+      }
       wallFatLo[k] = S->wallFat[k].lo;
       wallFatHi[k] = S->wallFat[k].hi;
     }
@@ -1830,15 +1838,13 @@ struct Env {
         // ~500x the float error of either evaluation) on the same side, the routine's answer is known without running it.
         bool knownSeparated = false;
         if ((deadQ >> pb_) & 1u) {
-          const Vec2 w0 = selGet(wallV0, pa_), w1 = selGet(wallV1, pa_);
+          const Vec2 w0 = selGet(wallV0, pa_);
           const float totalRadius = selGet(wallRad, pa_) + radiusOf(pb_);
           const float thr = Max(kLinearSlop, totalRadius - 3.0f * kLinearSlop) + 0.25f * kLinearSlop + 5.0e-4f;
-          const Vec2 ed = w1 - w0;
-          const float len2 = Dot(ed, ed);
-          const float inv = 1.0f / sqrtf(len2);
+          const Vec2 nrm = selGet(wallNrm, pa_), tan_ = selGet(wallTan, pa_);   // per-launch constants (see load)
           const Vec2 r0 = c0[b] - w0, r1 = c[b] - w0;
-          const float d0 = Cross(ed, r0) * inv, d1 = Cross(ed, r1) * inv;
-          const float u = Dot(r0, ed) / len2;
+          const float d0 = -Dot(r0, nrm), d1 = -Dot(r1, nrm);     // signed distances to the wall line (either orientation)
+          const float u = Dot(r0, tan_);                           // projection parameter of the start point on the segment
           knownSeparated = u > 0.01f && u < 0.99f && ((d0 > thr && d1 > thr) || (d0 < -thr && d1 < -thr));
         }
         if (knownSeparated) {
