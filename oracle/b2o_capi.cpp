@@ -239,6 +239,37 @@ void b2o_dump(b2o_env* e, float* bodies, float* joints, float* pairs) {
     }
 }
 
+// body-origin transforms (xf.p, xf.q.s, xf.q.c) and world-frame polygon vertices b2Mul(xf, v) — what lcd_render reads
+// (world_env.py:479,501-502); out: [nb,4] and [nb, 1 + 2*kMaxPolygonVertices] (count, then x,y pairs; count 0 = circle, then radius)
+void b2o_body_xf(b2o_env* e, float* xf_out, float* verts_out) {
+  const b2o_scene_desc& S = e->scene;
+  const int VS = 1 + 2 * kMaxPolygonVertices;
+  for (int i = 0; i < S.n_bodies; ++i) {
+    const Body& b = e->world.bodies[4 + i];
+    xf_out[4 * i] = b.xf.p.x; xf_out[4 * i + 1] = b.xf.p.y; xf_out[4 * i + 2] = b.xf.q.s; xf_out[4 * i + 3] = b.xf.q.c;
+    float* v = verts_out + (size_t)i * VS;
+    if (b.shape.type == kCircle) { v[0] = 0.0f; v[1] = b.shape.radius; continue; }
+    v[0] = (float)b.shape.count;
+    for (int k = 0; k < b.shape.count; ++k) {
+      Vec2 p = Mul(b.xf, b.shape.v[k]);
+      v[1 + 2 * k] = p.x; v[2 + 2 * k] = p.y;
+    }
+  }
+}
+
+// diagnostic: move one state scalar of one body by `ulps` float32 steps (0:c.x 1:c.y 2:a 3:v.x 4:v.y 5:w); used by
+// tools/nudge_search.py to localise WHEN a replay departs from a recording.
+void b2o_nudge(b2o_env* e, int32_t body, int32_t field, int32_t ulps) {
+  Body& b = e->world.bodies[4 + body];
+  float* f = field == 0 ? &b.sweep.c.x : field == 1 ? &b.sweep.c.y : field == 2 ? &b.sweep.a : field == 3 ? &b.v.x : field == 4 ? &b.v.y : &b.w;
+  for (int i = 0; i < (ulps < 0 ? -ulps : ulps); ++i) *f = nextafterf(*f, ulps > 0 ? INFINITY : -INFINITY);
+  if (field < 3) { b.sweep.c0 = b.sweep.c; b.sweep.a0 = b.sweep.a; b.SynchronizeTransform(); }
+}
+
+// variant switches of b2o_math.h (process-wide; tests that change them restore the defaults)
+void b2o_set_variant(int32_t key, int32_t value) { if (key >= 0 && key < kNumVariants) g_variant[key] = value; }
+int32_t b2o_get_variant(int32_t key) { return key >= 0 && key < kNumVariants ? g_variant[key] : -1; }
+
 void b2o_track_sweeps(b2o_env* e, int32_t on) { e->world.stats.trackSweeps = on != 0; }
 void b2o_sweep_hist(b2o_env* e, int64_t* out182) {
   for (int i = 0; i < 182; ++i) out182[i] = e->world.stats.sweepHist[i];

@@ -166,12 +166,36 @@ static inline void ShapeComputeMass(const Shape* s, MassData* md, float density)
     md->I = 0.0f;
     return;
   }
+  if (b2o_variant(4) == 2) {  // Box2D 2.2.1 form (reference point = origin, separate px/py terms)
+    Vec2 center = V2(0.0f, 0.0f);
+    float area = 0.0f, I = 0.0f;
+    const float k_inv3 = 1.0f / 3.0f;
+    for (int i = 0; i < s->count; ++i) {
+      Vec2 p1 = V2(0.0f, 0.0f), p2 = s->v[i], p3 = i + 1 < s->count ? s->v[i + 1] : s->v[0];
+      Vec2 e1 = p2 - p1, e2 = p3 - p1;
+      float D = Cross(e1, e2);
+      float triangleArea = 0.5f * D;
+      area += triangleArea;
+      center += triangleArea * k_inv3 * (p1 + p2 + p3);
+      float px = p1.x, py = p1.y, ex1 = e1.x, ey1 = e1.y, ex2 = e2.x, ey2 = e2.y;
+      float intx2 = k_inv3 * (0.25f * (ex1 * ex1 + ex2 * ex1 + ex2 * ex2) + (px * ex1 + px * ex2)) + 0.5f * px * px;
+      float inty2 = k_inv3 * (0.25f * (ey1 * ey1 + ey2 * ey1 + ey2 * ey2) + (py * ey1 + py * ey2)) + 0.5f * py * py;
+      I += D * (intx2 + inty2);
+    }
+    md->mass = density * area;
+    center *= 1.0f / area;
+    md->center = center;
+    md->I = density * I;
+    return;
+  }
   Vec2 center = V2(0.0f, 0.0f);
   float area = 0.0f;
   float I = 0.0f;
   Vec2 sref = V2(0.0f, 0.0f);
-  for (int i = 0; i < s->count; ++i) sref += s->v[i];
-  sref *= 1.0f / s->count;
+  if (b2o_variant(4) != 1) {
+    for (int i = 0; i < s->count; ++i) sref += s->v[i];
+    sref *= 1.0f / s->count;
+  }
   const float k_inv3 = 1.0f / 3.0f;
   for (int i = 0; i < s->count; ++i) {
     Vec2 e1 = s->v[i] - sref;
@@ -403,9 +427,82 @@ static inline void CollidePolygonAndCircle(Manifold* manifold, const Shape* poly
   }
 }
 
+// b2EdgeSeparation + b2FindMaxSeparation (b2CollidePolygon.cpp, Box2D 2.3.0 form: support vertex of poly2 for the edge
+// normal, separation measured in the world frame; hill climb from the edge facing the other centroid)
+static inline float EdgeSeparation230(const Shape* poly1, const Transform& xf1, int edge1, const Shape* poly2, const Transform& xf2) {
+  const Vec2* vertices1 = poly1->v;
+  const Vec2* normals1 = poly1->n;
+  int count2 = poly2->count;
+  const Vec2* vertices2 = poly2->v;
+  Vec2 normal1World = Mul(xf1.q, normals1[edge1]);
+  Vec2 normal1 = MulT(xf2.q, normal1World);
+  int index = 0;
+  float minDot = kMaxFloat;
+  for (int i = 0; i < count2; ++i) {
+    float dot = Dot(vertices2[i], normal1);
+    if (dot < minDot) {
+      minDot = dot;
+      index = i;
+    }
+  }
+  Vec2 v1 = Mul(xf1, vertices1[edge1]);
+  Vec2 v2 = Mul(xf2, vertices2[index]);
+  return Dot(v2 - v1, normal1World);
+}
+static inline float FindMaxSeparation230(int* edgeIndex, const Shape* poly1, const Transform& xf1, const Shape* poly2,
+                                         const Transform& xf2) {
+  int count1 = poly1->count;
+  const Vec2* normals1 = poly1->n;
+  Vec2 d = Mul(xf2, poly2->centroid) - Mul(xf1, poly1->centroid);
+  Vec2 dLocal1 = MulT(xf1.q, d);
+  int edge = 0;
+  float maxDot = -kMaxFloat;
+  for (int i = 0; i < count1; ++i) {
+    float dot = Dot(normals1[i], dLocal1);
+    if (dot > maxDot) {
+      maxDot = dot;
+      edge = i;
+    }
+  }
+  float s = EdgeSeparation230(poly1, xf1, edge, poly2, xf2);
+  int prevEdge = edge - 1 >= 0 ? edge - 1 : count1 - 1;
+  float sPrev = EdgeSeparation230(poly1, xf1, prevEdge, poly2, xf2);
+  int nextEdge = edge + 1 < count1 ? edge + 1 : 0;
+  float sNext = EdgeSeparation230(poly1, xf1, nextEdge, poly2, xf2);
+  int bestEdge;
+  float bestSeparation;
+  int increment;
+  if (sPrev > s && sPrev > sNext) {
+    increment = -1;
+    bestEdge = prevEdge;
+    bestSeparation = sPrev;
+  } else if (sNext > s) {
+    increment = 1;
+    bestEdge = nextEdge;
+    bestSeparation = sNext;
+  } else {
+    *edgeIndex = edge;
+    return s;
+  }
+  for (;;) {
+    if (increment == -1) edge = bestEdge - 1 >= 0 ? bestEdge - 1 : count1 - 1;
+    else edge = bestEdge + 1 < count1 ? bestEdge + 1 : 0;
+    s = EdgeSeparation230(poly1, xf1, edge, poly2, xf2);
+    if (s > bestSeparation) {
+      bestEdge = edge;
+      bestSeparation = s;
+    } else {
+      break;
+    }
+  }
+  *edgeIndex = bestEdge;
+  return bestSeparation;
+}
+
 // b2FindMaxSeparation (b2CollidePolygon.cpp, 2.3.1 form: brute force over poly1 edges x poly2 vertices)
 static inline float FindMaxSeparation(int* edgeIndex, const Shape* poly1, const Transform& xf1, const Shape* poly2,
                                       const Transform& xf2) {
+  if (b2o_variant(3) == 1) return FindMaxSeparation230(edgeIndex, poly1, xf1, poly2, xf2);
   int count1 = poly1->count;
   int count2 = poly2->count;
   const Vec2* n1s = poly1->n;
@@ -480,7 +577,8 @@ static inline void CollidePolygons(Manifold* manifold, const Shape* polyA, const
   int edge1;
   uint8_t flip;
   const float k_tol = 0.1f * kLinearSlop;
-  if (separationB > separationA + k_tol) {
+  const float k_relativeTol = 0.98f, k_absoluteTol = 0.001f;   // 2.3.0 rule
+  if (b2o_variant(3) == 1 ? (separationB > k_relativeTol * separationA + k_absoluteTol) : (separationB > separationA + k_tol)) {
     poly1 = polyB;
     poly2 = polyA;
     xf1 = xfB;

@@ -16,6 +16,8 @@
 #include <cstdint>
 #include <cstring>
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 
 namespace b2o {
 
@@ -88,7 +90,116 @@ static inline void sincosf_poly(double x, double x2, const SinCosTab* p, int n, 
   *cosp = (float)(c + x6 * c2);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// sinf / cosf of glibc <= 2.27 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h of 2.26/2.27 = the C form of the
+// x86_64 assembly used since 2.16): double-precision Chebyshev polynomials after a pi/2 table reduction.  This is the
+// libm of the Ubuntu-18.04-era stack the reference's recordings were made with (replay table).
+// ---------------------------------------------------------------------------------------------
+namespace g227 {
+static const double C0 = -0x1.ffffffffe98aep-2, C1 = 0x1.55555545c50c7p-5, C2 = -0x1.6c16b348b6874p-10,
+                    C3 = 0x1.a00eb9ac43ccp-16, C4 = -0x1.23c97dd8844d7p-22;
+static const double S0 = -0x1.5555555551cd9p-3, S1 = 0x1.1111110c2688bp-7, S2 = -0x1.a019f8b4bd1f9p-13,
+                    S3 = 0x1.71d7264e6b5b4p-19, S4 = -0x1.a947e1674b58ap-26;
+static const double SS0 = -0x1.555555543d49dp-3, SS1 = 0x1.110f475cec8c5p-7;
+static const double CC0 = -0x1.fffffff5cc6fdp-2, CC1 = 0x1.55514b178dac5p-5;
+static const double PI_2_hi = 0x1.921fb544p+0, PI_2_lo = 0x1.0b4611a626332p-34;
+static const double SMALL = 0x1p-50, inv_PI_4 = 0x1.45f306dc9c883p+0;
+static const double PIO4 = 0x1.921fb54442d18p-1;   // M_PI_4
+static const double PIO2 = 0x1.921fb54442d18p+0;   // M_PI_2
+static inline double pio2_table(unsigned k) { return (double)k * PIO2; }   // {0,1,2,3,4,5} * M_PI_2, each product exact-rounded as in the table
+static inline double sin_poly(double t, double t2) {
+  double cx = S3 + t2 * S4;
+  cx = S2 + t2 * cx;
+  cx = S1 + t2 * cx;
+  cx = S0 + t2 * cx;
+  return t + t * t2 * cx;
+}
+static inline double cos_poly(double t2) {
+  double cx = C3 + t2 * C4;
+  cx = C2 + t2 * cx;
+  cx = C1 + t2 * cx;
+  cx = C0 + t2 * cx;
+  return 1.0 + t2 * cx;
+}
+static inline float reduced_sin(double theta, unsigned n, unsigned signbit) {
+  const double theta2 = theta * theta;
+  double sign = (((n >> 2) & 1) ^ signbit) ? -1.0 : 1.0;
+  double sx = (n & 2) == 0 ? sin_poly(theta, theta2) : cos_poly(theta2);
+  return (float)(sign * sx);
+}
+static inline float reduced_cos(double theta, unsigned n) {
+  const double theta2 = theta * theta;
+  n += 2;
+  double sign = ((n >> 2) & 1) ? -1.0 : 1.0;
+  double cx = (n & 2) == 0 ? sin_poly(theta, theta2) : cos_poly(theta2);
+  return (float)(sign * cx);
+}
+// shared range reduction for PI/4 <= |x| < 2^23; returns theta, sets n
+static inline double reduce(double abstheta, unsigned* n_out) {
+  if (abstheta < 9 * PIO4) {
+    unsigned n = (unsigned)(abstheta * inv_PI_4) + 1;
+    *n_out = n;
+    return abstheta - pio2_table(n / 2);
+  }
+  unsigned n = ((unsigned)(abstheta * inv_PI_4)) + 1;
+  double x = (double)(n / 2);
+  *n_out = n;
+  return (abstheta - x * PI_2_hi) - x * PI_2_lo;
+}
+}  // namespace g227
+
+static inline float b2o_sinf_g227(float x) {
+  using namespace g227;
+  double theta = x, abstheta = theta < 0 ? -theta : theta;
+  if (abstheta < PIO4) {
+    if (abstheta >= 0x1p-5) return (float)sin_poly(theta, theta * theta);
+    if (abstheta >= 0x1p-27) {
+      const double theta2 = theta * theta;
+      double cx = SS0 + theta2 * SS1;
+      return (float)(theta + theta * theta2 * cx);
+    }
+    return theta != 0.0 ? (float)(theta - theta * SMALL) : x;
+  }
+  if (!(abstheta < 0x1p+23)) return (float)sin(theta);   // never reached by body angles
+  unsigned n;
+  double t = reduce(abstheta, &n);
+  return reduced_sin(t, n, x < 0.0f ? 1u : 0u);
+}
+static inline float b2o_cosf_g227(float x) {
+  using namespace g227;
+  double theta = x, abstheta = theta < 0 ? -theta : theta;
+  if (abstheta < PIO4) {
+    if (abstheta >= 0x1p-5) return (float)cos_poly(theta * theta);
+    if (abstheta >= 0x1p-27) {
+      const double theta2 = theta * theta;
+      double cx = CC0 + theta2 * CC1;
+      return (float)(1.0 + theta2 * cx);
+    }
+    return (float)(1.0 - abstheta);
+  }
+  if (!(abstheta < 0x1p+23)) return (float)cos(theta);
+  unsigned n;
+  double t = reduce(abstheta, &n);
+  return reduced_cos(t, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variant switches.  The DEFAULTS are the set that reproduces the reference's recordings from the recorder's own inputs
+// (tests/test_oracle_replay.py, DESIGN.md "replay table"): pybox2d 2.3.10 bundles Box2D 2.3.0, run on a glibc <= 2.27 libm.
+// The alternatives are kept so that the table in DESIGN.md can be regenerated (tools/replay_gifs.py --table).
+//   0 sincos      2 = glibc<=2.27 (default)  0 = glibc>=2.28   1 = (float)sin((double)x)
+//   1 damping     1 = Box2D 2.3.0 `v *= clamp(1 - h*c, 0, 1)` (default)   0 = >=2.3.1 Pade `v *= 1/(1 + h*c)`
+//   2 advance     1 = Box2D 2.3.0 `c0 = (1-beta)*c0 + beta*c` (default)   0 = >=2.3.1 `c0 += beta*(c - c0)`
+//   3 polygons    1 = Box2D 2.3.0 b2FindMaxSeparation hill climb + 0.98/0.001 face rule (default)   0 = >=2.3.1 brute force + k_tol
+//   4 polygon mass reference point   0 = vertex mean (default)   1 = origin   2 = Box2D 2.2.1 formula
+// ---------------------------------------------------------------------------------------------
+enum { kVarSinCos = 0, kVarDamping = 1, kVarAdvance = 2, kVarPolygons = 3, kVarMassRef = 4, kNumVariants = 8 };
+inline int g_variant[kNumVariants] = {2, 1, 1, 1, 0, 0, 0, 0};
+static inline int b2o_variant(int k) { return g_variant[k]; }
 static inline void b2o_sincosf(float y, float* sinp, float* cosp) {
+  if (b2o_variant(0) == 1) { *sinp = (float)sin((double)y); *cosp = (float)cos((double)y); return; }
+  if (b2o_variant(0) == 2) { *sinp = b2o_sinf_g227(y); *cosp = b2o_cosf_g227(y); return; }
   double x = y;
   double s;
   int n;
@@ -301,8 +412,13 @@ struct Sweep {
   }
   void Advance(float alpha) {
     float beta = (alpha - alpha0) / (1.0f - alpha0);
-    c0 += beta * (c - c0);
-    a0 += beta * (a - a0);
+    if (b2o_variant(2) == 1) {  // Box2D 2.3.0: lerp form
+      c0 = (1.0f - beta) * c0 + beta * c;
+      a0 = (1.0f - beta) * a0 + beta * a;
+    } else {                    // Box2D >= 2.3.1
+      c0 += beta * (c - c0);
+      a0 += beta * (a - a0);
+    }
     alpha0 = alpha;
   }
   void Normalize() {

@@ -1180,8 +1180,13 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
     if (b.type == kDynamicBody) {
       v += h * (1.0f * gravity + b.invMass * V2(0.0f, 0.0f));
       w += h * b.invI * 0.0f;
-      v *= 1.0f / (1.0f + h * b.linearDamping);
-      w *= 1.0f / (1.0f + h * b.angularDamping);
+      if (b2o_variant(1) == 1) {  // Box2D 2.3.0 / 2.2.x: first-order Taylor form
+        v *= Clamp(1.0f - h * b.linearDamping, 0.0f, 1.0f);
+        w *= Clamp(1.0f - h * b.angularDamping, 0.0f, 1.0f);
+      } else {                    // Box2D >= 2.3.1: Pade form
+        v *= 1.0f / (1.0f + h * b.linearDamping);
+        w *= 1.0f / (1.0f + h * b.angularDamping);
+      }
     }
     positions[i].c = c;
     positions[i].a = a;

@@ -95,6 +95,20 @@ class OracleEnv:
     self.lib.b2o_dump(self._e, _p(b), _p(j), _p(p))
     return b, j[:self.nj], p[:self.n_pairs]
 
+  def nudge(self, body, field, ulps):
+    self.lib.b2o_nudge(self._e, int(body), int(field), int(ulps))
+
+  def body_xf(self):
+    """(xf [nb,4] = p.x,p.y,q.s,q.c ; shapes list of ('circle', r) | ('poly', world verts [k,2])) as lcd_render reads them."""
+    xf = np.zeros((self.nb, 4), np.float32)
+    vs = np.zeros((self.nb, 33), np.float32)
+    self.lib.b2o_body_xf(self._e, _p(xf), _p(vs))
+    shapes = []
+    for i in range(self.nb):
+      k = int(vs[i, 0])
+      shapes.append(('circle', float(vs[i, 1])) if k == 0 else ('poly', vs[i, 1:1 + 2 * k].reshape(k, 2).copy()))
+    return xf, shapes
+
   def stats(self):
     s = np.zeros(6, np.int64)
     self.lib.b2o_stats(self._e, _p(s))
@@ -104,6 +118,28 @@ class OracleEnv:
     o = np.zeros(64, np.int32)
     n = self.lib.b2o_contact_order(self._e, _p(o), 64)
     return o[:n]
+
+
+VARIANT_KEYS = {'sincos': 0, 'damping': 1, 'advance': 2, 'polygons': 3, 'massref': 4}
+VARIANT_DEFAULTS = {'sincos': 2, 'damping': 1, 'advance': 1, 'polygons': 1, 'massref': 0}
+
+
+class variants:
+  """with pyb2o.variants(damping=0, ...): ...  — temporarily switch oracle variants (see b2o_math.h); restores defaults."""
+
+  def __init__(self, **kw):
+    self.kw = kw
+
+  def __enter__(self):
+    lib = load()
+    for k, v in self.kw.items():
+      lib.b2o_set_variant(VARIANT_KEYS[k], int(v))
+    return self
+
+  def __exit__(self, *a):
+    lib = load()
+    for k, v in VARIANT_DEFAULTS.items():
+      lib.b2o_set_variant(VARIANT_KEYS[k], int(v))
 
 
 def render_poses(desc, poses, shape_sel=None):

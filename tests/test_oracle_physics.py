@@ -1,12 +1,7 @@
-"""CPU oracle pinned against (1) the reference's published GIF frames (tests/golden/gif_lcd_frames.npz, decoded from
-/root/reference/assets/envs/*.gif by tools/gen_gif_fixtures.py), (2) analytic known answers, (3) glibc for sincosf."""
+"""CPU oracle pinned against analytic known answers and libm (the reference's recordings: tests/test_oracle_replay.py)."""
 import numpy as np
 import pytest
 import boxlcd_amd as B
-
-
-def _gif(name, w):
-  return np.unpackbits(np.load('tests/golden/gif_lcd_frames.npz')[name], axis=-1)[:, :, :w].astype(np.uint8)
 
 
 def _env(oracle, name, pose, variant=0):
@@ -14,147 +9,6 @@ def _env(oracle, name, pose, variant=0):
   o = oracle.OracleEnv(env.scene.desc)
   o.reset(np.asarray(pose, np.float32))
   return env, o
-
-
-@pytest.mark.parametrize('variant', [0, 1])
-def test_dropbox_gif_all_26_frames(oracle, variant):
-  """Reference output pin: from the fitted start pose (tools/fit_gif_dropbox.py) the oracle reproduces every LCD frame of
-  assets/envs/Dropbox.gif: free fall, TOI landing on a corner, tumble, frictional slide, rest, sleep."""
-  gif = _gif('Dropbox', 16)
-  _, o = _env(oracle, 'Dropbox', [[1.66, 4.015, 1.315]], variant)
-  for t in range(26):
-    o.step(np.zeros(1, np.float32))
-    assert (o.render() == gif[t]).all(), f'frame {t}'
-
-
-def test_bounce_gif_all_50_frames(oracle):
-  """Reference output pin: assets/envs/Bounce.gif, four bounces with restitution 0.8 resolved by the TOI solver."""
-  gif = _gif('Bounce', 16)
-  _, o = _env(oracle, 'Bounce', [[1.55, 4.17, 0.0]])
-  for t in range(50):
-    o.step(np.zeros(1, np.float32))
-    assert (o.render() == gif[t]).all(), f'frame {t}'
-
-
-@pytest.mark.parametrize('env_name,key,start', [
-    ('Bounce2', 'Bounce2', [[1.60323, 4.17499, 0.0], [2.47265, 3.01481, 0.0]]),
-    ('Object2', 'Object2_circles', [[3.7294, 2.56002, 0.0], [3.58992, 0.70644, 0.0]]),
-])
-def test_two_ball_gifs_all_50_frames(oracle, env_name, key, start):
-  """Reference output pin for dynamic-vs-dynamic contacts: assets/envs/Bounce2.gif (ball-ball contact touching at frames 7 and
-  33-38, fitted by tools/fit_gif_two_bodies.py) and Object2-circles.gif: b2CollideCircles and two-body islands."""
-  gif = _gif(key, 16)
-  env = getattr(B.envs, env_name)()
-  o = oracle.OracleEnv(env.scene.desc)
-  o.reset(np.asarray(start, np.float32), [0, 0])
-  touched = False
-  for t in range(50):
-    o.step(np.zeros(1, np.float32))
-    assert (o.render() == gif[t]).all(), f'frame {t}'
-    touched = touched or o.dump()[2][8, 1] > 0
-  if key == 'Bounce2':
-    assert touched
-
-
-def _gif_pin(oracle, env_name, key, start, sel):
-  gif = _gif(key, 16)
-  env = getattr(B.envs, env_name)()
-  o = oracle.OracleEnv(env.scene.desc)
-  o.reset(np.array(start, np.float32).reshape(-1, 3), sel)
-  bad, body_body = [], 0
-  for t in range(len(gif)):
-    o.step(np.zeros(1, np.float32))
-    bad.append(int((o.render() != gif[t]).sum()))
-    body_body += int(o.dump()[2][-1, 1] > 0)          # last pair slot = (object0, object1)
-  return bad, body_body
-
-
-# Start poses below were found with the HIP path as a 10^6-wide parallel search (tools/fit_gif_gpu.py) and are float32 values;
-# the assertion itself is CPU-only: the oracle, started there, reproduces the reference's GIF frame for frame.
-BOX_AND_BALL_START = [[1.602295160293579, 4.1801910400390625, 1.3021485805511475], [2.4775490760803223, 3.016671895980835, 0.0]]
-CUBES_START = [[0.8717406392097473, 2.3443641662597656, 0.5894299745559692], [1.8817998170852661, 4.431509971618652, -0.22333171963691711]]
-
-
-def test_box_and_ball_gif_exact(oracle):
-  """assets/envs/Object2.gif (a box and a ball, both e=0.8): the box hits the ball in flight at frame 7
-  (b2CollidePolygonAndCircle), bounces and tumbles on two-point manifolds with restitution.  All 50 frames identical."""
-  bad, body_body = _gif_pin(oracle, 'Object2', 'Object2', BOX_AND_BALL_START, [1, 0])
-  assert sum(bad) == 0 and body_body >= 1, bad
-
-
-def test_cubes_gif_exact(oracle):
-  """assets/envs/Object2_cubes.gif (two boxes): box-box contacts (b2CollidePolygons: FindMaxSeparation, incident edge,
-  clipping; 2-point block solver, TOI against walls) - all 50 frames identical."""
-  bad, body_body = _gif_pin(oracle, 'Object2', 'Object2_cubes', CUBES_START, [1, 1])
-  assert sum(bad) == 0 and body_body >= 2, bad
-
-
-# ---- robot GIFs: revolute joints, motors, limits ---------------------------------------------------------------------
-# The reference's demo recorder (research/scripts/evaluations/demo_imgs.py:60-72) seeds the env with 7 and feeds
-# np.random.RandomState(4).uniform(-1, 1, act_dim) every step.  With that action tape and the seed-7 reset sample (refined
-# by <= 1e-3 with tools/fit_gif_gpu.py; stored in tests/golden/gif_robot_starts.json) the oracle reproduces the robot
-# recordings.  They were rendered with the Pillow of 2021 (raster variant 2: see oracle/b2o_raster.h), which only
-# matters where a thin link truncates to a degenerate polygon.
-def _robot_gif(oracle, name):
-  import json
-  start = json.load(open('tests/golden/gif_robot_starts.json'))[name]
-  env = getattr(B.envs, name)(raster_variant=2)
-  gif = _gif(name, env.scene.desc.lcd_w)
-  o = oracle.OracleEnv(env.scene.desc)
-  o.reset(np.array(start, np.float32), [0] * len(start))
-  rs = np.random.RandomState(4)
-  bad, limit_frames = [], 0
-  for t in range(len(gif)):
-    o.step(rs.uniform(-1, 1, env.act_size).astype(np.float32))
-    bad.append(int((o.render() != gif[t]).sum()))
-    limit_frames += int((o.dump()[1][:, 4] != 0).any())
-  return bad, limit_frames
-
-
-def test_urchin_gif_exact(oracle):
-  """assets/envs/Urchin.gif: 3 motorised, limited revolute joints under random torques, 4-body island on the floor -
-  100/100 frames identical (b2RevoluteJoint motor + limit + point constraint, joint/contact ordering, island solve)."""
-  bad, limit_frames = _robot_gif(oracle, 'Urchin')
-  assert sum(bad) == 0 and limit_frames > 10, (bad, limit_frames)
-
-
-def test_urchin_ball_gif_exact(oracle):
-  """assets/envs/UrchinBall.gif: the same robot kicking a ball - 150/150 frames identical."""
-  bad, _ = _robot_gif(oracle, 'UrchinBall')
-  assert sum(bad) == 0, bad
-
-
-def test_luxo_gifs_near_exact(oracle):
-  """Luxo.gif (100 frames) and LuxoBall.gif (150): identical except the frame where the lamp's flat foot is pressed
-  against the left wall (6 px: the recording draws the foot's degenerate polygon there, our variant 2 does not) and one
-  more pixel in LuxoBall.  The dynamics (limits at +-0.5..., 5-vertex lamp head) are reproduced to the last frame."""
-  bad, _ = _robot_gif(oracle, 'Luxo')
-  assert sum(bad) == 6 and bad[37] == 6, bad
-  bad, limit_frames = _robot_gif(oracle, 'LuxoBall')
-  assert sum(bad) <= 7 and sum(b == 0 for b in bad) >= 148 and limit_frames > 10, bad
-
-
-def test_urchin_cube_gif_prefix(oracle):
-  """UrchinCube.gif: robot + box; identical for the first 99 frames and 121 of 150 overall (then the fit's residual start
-  error is amplified by the box's tumbling - chaotic, not a modelling difference: the other recordings stay exact)."""
-  bad, _ = _robot_gif(oracle, 'UrchinCube')
-  assert sum(bad[:99]) == 0 and sum(b == 0 for b in bad) >= 120, bad
-
-
-def test_seed7_reset_sample_matches_recordings():
-  """The recordings' fitted start poses coincide with OUR restatement of gym-0.17 seeding + the reference's sampling order
-  (world_env.py:197-304) for seed 7 - a pin of np_random()/_sample_poses() (no GPU, no oracle needed)."""
-  import json
-  starts = json.load(open('tests/golden/gif_robot_starts.json'))
-  starts['Bounce2'] = [[1.60323, 4.17499, 0.0], [2.47265, 3.01481, 0.0]]
-  for name, fit in starts.items():
-    env = getattr(B.envs, name)()
-    env.seed(7)
-    poses, _ = env._sample_poses(lambda lo, hi: np.array([env.np_random.uniform(lo, hi)]), 1)
-    d = np.abs(poses[0, :, :2] - np.array(fit)[:, :2]).max()
-    assert d < 6e-3, (name, d)
-    if name != 'Bounce2':
-      assert np.abs(poses[0, :, 2] - np.array(fit)[:, 2]).max() < 1e-2, name
 
 
 def test_free_fall_increments(oracle):
@@ -225,19 +79,26 @@ def test_mass_data_known_answers(oracle):
   assert area2 > 0 and abs(m[0] - 0.1 * area2 / 2) < 1e-6 and abs(m[1]) > 1e-3   # non-zero centroid
 
 
-def test_sincos_matches_glibc(oracle):
-  """The restated sincosf equals this container's glibc on all but ~1e-8 of inputs (glibc's FMA ifunc variant)."""
+def test_sincos_variants(oracle):
+  """Default sincos = glibc <= 2.27's algorithm (the libm the exactly-reproduced recordings were made with): double-precision
+  Chebyshev polynomials, correctly rounded on all but ~1e-7 of inputs.  Variant 0 = glibc >= 2.28's algorithm, checked against
+  this container's glibc (it differs only through glibc's FMA ifunc build, ~1e-8 of inputs)."""
   rng = np.random.RandomState(0)
-  x = np.concatenate([rng.uniform(-130, 130, 2_000_000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, 0.75, 119.99, 120.0, 1e5, -3e7]]).astype(np.float32)
+  x = np.concatenate([rng.uniform(-130, 130, 2_000_000), rng.uniform(-1e-3, 1e-3, 1000), rng.uniform(-0.04, 0.04, 100000),
+                      [0.0, -0.0, 0.75, 119.99, 120.0, 1e5, -3e7, 0.7853981, 0.7853982, 7.0685835, 7.068584]]).astype(np.float32)
   s, c = oracle.sincos(x)
+  rs, rc = np.sin(x.astype(np.float64)).astype(np.float32), np.cos(x.astype(np.float64)).astype(np.float32)
+  assert (s != rs).sum() <= 3 and (c != rc).sum() <= 3, ((s != rs).sum(), (c != rc).sum())
+  assert np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64))).max() < 6e-8
+  with oracle.variants(sincos=0):
+    s, c = oracle.sincos(x)
   import ctypes, ctypes.util
   libm = ctypes.CDLL(ctypes.util.find_library('m'))
   libm.sinf.restype = ctypes.c_float; libm.sinf.argtypes = [ctypes.c_float]
   libm.cosf.restype = ctypes.c_float; libm.cosf.argtypes = [ctypes.c_float]
-  idx = rng.randint(0, len(x), 20000).tolist() + list(range(len(x) - 1007, len(x)))
+  idx = rng.randint(0, len(x), 20000).tolist() + list(range(len(x) - 1011, len(x)))
   bad = sum((libm.sinf(float(x[i])) != s[i]) or (libm.cosf(float(x[i])) != c[i]) for i in idx)
   assert bad <= 1
-  # and agrees with float64 numpy to float32 rounding everywhere
   assert np.abs(s - np.sin(x.astype(np.float64))).max() < 6e-8 and np.abs(c - np.cos(x.astype(np.float64))).max() < 6e-8
 
 

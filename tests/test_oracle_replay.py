@@ -1,0 +1,66 @@
+"""The CPU oracle against the reference's published recordings, replayed from the RECORDER'S OWN INPUTS: env.seed(S) reset
+sample + RandomState(A) action tape (reference research/scripts/evaluations/demo_imgs.py:58-72; tests/replay.py).  No start
+pose is fitted anywhere.  LCD frames use the oracle's raster (variant 2); the 8x RGB view is drawn with the installed Pillow.
+
+What reproduces them (DESIGN.md §2 has the full switch table; tools/replay_gifs.py --table regenerates it):
+  pybox2d 2.3.10 bundles **Box2D 2.3.0** — first-order damping `v *= clamp(1 - h*c, 0, 1)`, `b2Sweep::Advance` as a lerp,
+  hill-climbing b2FindMaxSeparation with the 0.98/0.001 reference-face rule — and the recordings below marked EXACT were made
+  on a **glibc <= 2.27 libm** (sinf/cosf correctly rounded but for ~1e-7 of inputs).  Child links are placed with pybox2d's
+  float32 b2Vec2 arithmetic (world_env.py:250)."""
+import numpy as np
+import pytest
+import replay as R
+
+EXACT = ['Dropbox', 'Bounce', 'Bounce2', 'Object2', 'Object2_circles', 'Object2_cubes', 'UrchinBall']
+
+
+@pytest.mark.parametrize('gif', EXACT)
+def test_recording_reproduced_exactly_from_recorder_inputs(oracle, gif):
+  """Every LCD frame AND every 8x RGB frame (25.6-27.4 px/unit) of the recording, 26-150 frames, chaotic for the robots."""
+  bad_lcd, bad_rgb = R.replay(gif, oracle)
+  assert sum(bad_lcd) == 0, R.summary(bad_lcd)
+  assert sum(bad_rgb) == 0, R.summary(bad_rgb)
+
+
+def test_urchin_cube_recording(oracle):
+  """UrchinCube.gif (robot + damped box, limb-box b2CollidePolygons): all 150 LCD frames; the 8x view differs in 4 late frames."""
+  bad_lcd, bad_rgb = R.replay('UrchinCube', oracle)
+  assert sum(bad_lcd) == 0, R.summary(bad_lcd)
+  s = R.summary(bad_rgb)
+  assert s['exact'] >= 146 and s['first_miss'] >= 142, s
+
+
+def test_box2d_230_forms_are_what_the_recordings_need(oracle):
+  """Each Box2D >= 2.3.1 form, switched on alone, breaks a recording that the 2.3.0 form reproduces exactly."""
+  with oracle.variants(damping=0):
+    assert R.summary(R.replay('UrchinCube', oracle, want_rgb=False)[0])['first_miss'] == 4     # cube falls with Pade damping
+  with oracle.variants(polygons=0):
+    assert R.summary(R.replay('UrchinCube', oracle, want_rgb=False)[0])['exact'] < 150
+  with oracle.variants(advance=0):
+    assert R.summary(R.replay('Object2_cubes', oracle, want_rgb=False)[0])['exact'] < 50
+    assert R.summary(R.replay('UrchinBall', oracle, want_rgb=False)[0])['exact'] < 150
+  with oracle.variants(sincos=0):
+    assert R.summary(R.replay('UrchinBall', oracle, want_rgb=False)[0])['exact'] < 150
+
+
+def test_open_recordings_tracking(oracle):
+  """NOT reproduced to the end (tracked, not hidden): Urchin.gif, Luxo.gif, LuxoBall.gif, LuxoCube.gif.  They are exact at
+  25.6 px/unit for their first 17 / 66 / 57 / 33 frames and then drift (chaos amplifies an ulp-level difference); all four
+  score better with the glibc >= 2.28 sincos than the seven exact recordings do, i.e. they look like they were recorded on a
+  second machine (newer libm) with one more, unidentified, ulp-level difference — no switch combination reproduces them
+  (DESIGN.md §2).  Luxo frame 37 / LuxoBall frame 38 additionally differ by the 6-px degenerate foot polygon at (0,0),
+  which the recordings' Pillow draws and no characterised raster variant does."""
+  s = R.summary(R.replay('Urchin', oracle)[1]);   assert s['first_miss'] >= 17, s
+  bl, br = R.replay('Luxo', oracle)
+  assert R.summary(bl)['exact'] >= 95 and bl[37] == 6 and R.summary(br)['first_miss'] >= 66
+  bl, br = R.replay('LuxoBall', oracle)
+  assert R.summary(bl)['exact'] >= 100 and bl[38] == 6 and R.summary(br)['first_miss'] >= 57
+  with oracle.variants(sincos=0):
+    s = R.summary(R.replay('LuxoCube', oracle, want_rgb=False)[0]);   assert s['exact'] >= 132, s
+
+
+def test_seed7_sample_is_the_recordings_start(oracle):
+  """One env step from the unrefined seed-S sample equals frame 0 of every recording at 8x resolution."""
+  for gif in R.GIFS:
+    bad_lcd, bad_rgb = R.replay(gif, oracle, frames=1)
+    assert bad_lcd == [0] and bad_rgb == [0], gif

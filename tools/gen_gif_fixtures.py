@@ -11,12 +11,22 @@ import numpy as np
 from PIL import Image, ImageSequence
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PALETTE = [(254, 254, 254), (128, 102, 230), (77, 77, 128), (230, 102, 102), (128, 77, 128)]   # bg, object fill/outline, robot fill/outline
 out = {}
+rgb8 = {}
 for path in sorted(glob.glob('/root/reference/assets/envs/*.gif')):
   name = os.path.splitext(os.path.basename(path))[0].replace('-', '_')
   im = Image.open(path)
   frames = []
+  halves = []
   for fr in ImageSequence.Iterator(im):
+    c = np.asarray(fr.convert('RGB'))
+    half = c[:, :c.shape[1] // 2]
+    idx = np.full(half.shape[:2], 255, np.uint8)
+    for k, col in enumerate(PALETTE):
+      idx[(half == np.array(col, np.uint8)).all(-1)] = k
+    assert (idx != 255).all(), (name, 'unexpected colour in the 8x view')
+    halves.append(idx)
     g = np.asarray(fr.convert('L'))
     H, Wg = g.shape
     Wh = Wg // 2
@@ -31,5 +41,8 @@ for path in sorted(glob.glob('/root/reference/assets/envs/*.gif')):
         assert b.all() or not b.any(), (name, r, c)
     frames.append(np.packbits(lcd, axis=-1))
   out[name] = np.stack(frames)
-  print(name, out[name].shape)
+  rgb8[name] = np.stack(halves)
+  print(name, out[name].shape, rgb8[name].shape)
 np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'gif_lcd_frames.npz'), **out)
+# the left half of every frame = lcd_render(8W, 8H, 'RGB') of the same state (world_env.py:525), as palette indices
+np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'gif_rgb8_frames.npz'), palette=np.array(PALETTE, np.uint8), **rgb8)
