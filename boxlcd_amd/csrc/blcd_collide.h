@@ -430,32 +430,81 @@ BLCD_HD static inline void CollidePolygonAndCircle(Manifold* manifold, const Sha
   }
 }
 
-// b2FindMaxSeparation (b2CollidePolygon.cpp, 2.3.1 form: brute force over poly1 edges x poly2 vertices)
+// b2FindMaxSeparation + b2EdgeSeparation (b2CollidePolygon.cpp, Box2D 2.3.0): separation of poly2 from edge e of poly1 =
+// Dot(xf2*v2[support] - xf1*v1[e], n1World[e]) with the support vertex chosen in poly2's frame; the edge is found by a hill
+// climb that starts at the edge whose normal faces poly2's centroid.  The separation of an edge is a pure function of the
+// pose, so this kernel-side formulation evaluates all (<= 8) edges branch-free first - poly2's world vertices once - and
+// then replays the climb's decisions on that table; the oracle evaluates lazily like upstream.
 BLCD_HD static inline float FindMaxSeparation(int* edgeIndex, const Shape* poly1, const Transform& xf1, const Shape* poly2,
                                       const Transform& xf2) {
-  int count1 = poly1->count;
-  int count2 = poly2->count;
-  const Vec2* n1s = poly1->n;
-  const Vec2* v1s = poly1->v;
-  const Vec2* v2s = poly2->v;
-  Transform xf = MulT(xf2, xf1);
-  int bestIndex = 0;
-  float maxSeparation = -kMaxFloat;
-  for (int i = 0; i < count1; ++i) {
-    Vec2 n = Mul(xf.q, n1s[i]);
-    Vec2 v1 = Mul(xf, v1s[i]);
-    float si = kMaxFloat;
-    for (int j = 0; j < count2; ++j) {
-      float sij = Dot(n, v2s[j] - v1);
-      if (sij < si) si = sij;
+  const int count1 = poly1->count, count2 = poly2->count;
+  Vec2 w2[kShapeVerts];
+  for (int j = 0; j < kShapeVerts; ++j)
+    if (j < count2) w2[j] = Mul(xf2, poly2->v[j]);
+  float sep[kShapeVerts];
+  for (int e = 0; e < kShapeVerts; ++e) {
+    if (e >= count1) continue;
+    const Vec2 nW = Mul(xf1.q, poly1->n[e]);
+    const Vec2 nL = MulT(xf2.q, nW);
+    int support = 0;
+    float lowest = kMaxFloat;
+    for (int j = 0; j < kShapeVerts; ++j) {
+      if (j >= count2) continue;
+      const float d = Dot(poly2->v[j], nL);
+      if (d < lowest) {
+        lowest = d;
+        support = j;
+      }
     }
-    if (si > maxSeparation) {
-      maxSeparation = si;
-      bestIndex = i;
+    Vec2 far = w2[0];
+    for (int j = 1; j < kShapeVerts; ++j)
+      if (j == support) far = w2[j];
+    sep[e] = Dot(far - Mul(xf1, poly1->v[e]), nW);
+  }
+  auto at = [&](int e) {
+    float r = sep[0];
+    for (int k = 1; k < kShapeVerts; ++k)
+      if (k == e) r = sep[k];
+    return r;
+  };
+  // starting edge: normal with the largest projection on the centroid offset (poly1 frame)
+  const Vec2 dLocal1 = MulT(xf1.q, Mul(xf2, poly2->centroid) - Mul(xf1, poly1->centroid));
+  int edge = 0;
+  float maxDot = -kMaxFloat;
+  for (int i = 0; i < kShapeVerts; ++i) {
+    if (i >= count1) continue;
+    const float dot = Dot(poly1->n[i], dLocal1);
+    if (dot > maxDot) {
+      maxDot = dot;
+      edge = i;
     }
   }
-  *edgeIndex = bestIndex;
-  return maxSeparation;
+  const int prevEdge = edge - 1 >= 0 ? edge - 1 : count1 - 1;
+  const int nextEdge = edge + 1 < count1 ? edge + 1 : 0;
+  const float s = at(edge), sPrev = at(prevEdge), sNext = at(nextEdge);
+  int best, step;
+  float bestSep;
+  if (sPrev > s && sPrev > sNext) {
+    step = -1;
+    best = prevEdge;
+    bestSep = sPrev;
+  } else if (sNext > s) {
+    step = 1;
+    best = nextEdge;
+    bestSep = sNext;
+  } else {
+    *edgeIndex = edge;
+    return s;
+  }
+  for (int it = 0; it < kShapeVerts; ++it) {   // the climb visits each edge at most once
+    const int e = step < 0 ? (best - 1 >= 0 ? best - 1 : count1 - 1) : (best + 1 < count1 ? best + 1 : 0);
+    const float se = at(e);
+    if (!(se > bestSep)) break;
+    best = e;
+    bestSep = se;
+  }
+  *edgeIndex = best;
+  return bestSep;
 }
 
 // b2FindIncidentEdge (b2CollidePolygon.cpp)
@@ -506,8 +555,7 @@ BLCD_HD static inline void CollidePolygons(Manifold* manifold, const Shape* poly
   Transform xf1, xf2;
   int edge1;
   uint8_t flip;
-  const float k_tol = 0.1f * kLinearSlop;
-  if (separationB > separationA + k_tol) {
+  if (separationB > 0.98f * separationA + 0.001f) {   // Box2D 2.3.0: k_relativeTol, k_absoluteTol
     poly1 = polyB;
     poly2 = polyA;
     xf1 = xfB;

@@ -1,8 +1,9 @@
 // blcd_math.h — float32 math layer of the HIP product (host+device), Box2D 2.3.x b2Math.h semantics.
 // Reference path: the arithmetic under `b2World.Step` called at boxLCD/world_env.py:448-450 (Box2D is un-vendored).
 // Compile with -ffp-contract=off: Box2D's x86-64 builds have no FMA contraction and parity is bit-exact.
-// sincosf is our own double-precision-polynomial implementation (same published algorithm as glibc >= 2.28), so that
-// host setup code, device kernels and the parity oracle all agree bit for bit.
+// Version forms follow Box2D 2.3.0, the snapshot pybox2d 2.3.10 bundles (established by replaying the reference's recordings,
+// DESIGN.md §2).  sincosf is our own restatement of glibc <= 2.27's algorithm, so that host setup code, device kernels and the
+// parity oracle all agree bit for bit.
 #define BLCD_HD __host__ __device__
 #pragma once
 #include <hip/hip_runtime.h>
@@ -40,10 +41,11 @@ constexpr float kLinearSleepTolerance = 0.01f;
 constexpr float kAngularSleepTolerance = 2.0f / 180.0f * kPi;
 
 // ---------------------------------------------------------------------------------------------
-// sincosf: double-precision polynomial evaluation after a 2/pi reduction (the published algorithm glibc >= 2.28 and
-// the ARM optimized routines use).  Written table-free so the same source runs on host and device: the second
-// coefficient table of that algorithm is the first with the cosine polynomial negated, and the quadrant sign
-// multiplies an odd polynomial, so both reduce to exact sign flips of the results.
+// sincosf = sinf/cosf of glibc <= 2.27 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c: the C form of the x86-64 assembly glibc
+// used from 2.16): double-precision Chebyshev polynomials on |t| <= pi/4 after subtracting a multiple of pi/2.  This is the
+// libm under the reference recordings that replay exactly from the recorder's inputs; results are correctly
+// rounded for all but ~1e-7 of inputs.  Table-free and branch-light so the same source runs on host and device.
+// Domain: |y| < 2^23 (body angles never leave it); beyond that both results are y - y.
 // ---------------------------------------------------------------------------------------------
 BLCD_HD static inline uint32_t asuint(float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -54,92 +56,66 @@ BLCD_HD static inline uint32_t asuint(float f) {
   return u;
 #endif
 }
-BLCD_HD static inline uint32_t abstop12(float x) { return (asuint(x) >> 20) & 0x7ff; }
 
-// sin and cos polynomials on the reduced argument (|x| <= pi/4), x2 = x*x
-BLCD_HD static inline void sincos_poly(double x, double x2, float* sinv, float* cosv) {
-  const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
-               c4 = 0x1.99343027bf8c3p-16;
-  const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
-  double x3, x4, x5, x6, s, c, c1_, c2_, s1_;
-  x4 = x2 * x2;
-  x3 = x2 * x;
-  c2_ = c3 + x2 * c4;
-  s1_ = s2 + x2 * s3;
-  c1_ = c0 + x2 * c1;
-  x5 = x3 * x2;
-  x6 = x4 * x2;
-  s = x + x3 * s1;
-  c = c1_ + x4 * c2;
-  *sinv = (float)(s + x5 * s1_);
-  *cosv = (float)(c + x6 * c2_);
+BLCD_HD static inline double sc_sin_poly(double t, double t2) {   // t + t^3 (S0 + t^2 (S1 + t^2 (S2 + t^2 (S3 + t^2 S4))))
+  double p = 0x1.71d7264e6b5b4p-19 + t2 * -0x1.a947e1674b58ap-26;
+  p = -0x1.a019f8b4bd1f9p-13 + t2 * p;
+  p = 0x1.1111110c2688bp-7 + t2 * p;
+  p = -0x1.5555555551cd9p-3 + t2 * p;
+  return t + t * t2 * p;
+}
+BLCD_HD static inline double sc_cos_poly(double t2) {             // 1 + t^2 (C0 + t^2 (C1 + t^2 (C2 + t^2 (C3 + t^2 C4))))
+  double p = 0x1.a00eb9ac43ccp-16 + t2 * -0x1.23c97dd8844d7p-22;
+  p = -0x1.6c16b348b6874p-10 + t2 * p;
+  p = 0x1.55555545c50c7p-5 + t2 * p;
+  p = -0x1.ffffffffe98aep-2 + t2 * p;
+  return 1.0 + t2 * p;
 }
 
-// Out of line unless BLCD_SINCOS_INLINE: the circles-only step kernels need sincosf only on cold paths, and 58 inlined
-// copies (~250 instructions each) were a third of a kernel that is already far larger than the instruction cache
-// (measured: Bounce +6 %).  Kernels that call it in hot loops (general classes: position solver, TOI of polygons) define
-// BLCD_SINCOS_INLINE - out of line costs them 5-12 %.
+// Out of line unless BLCD_SINCOS_INLINE: the circles-only step kernels need sincosf only on cold paths, and dozens of
+// inlined copies were a third of a kernel that is already far larger than the instruction cache (measured: Bounce +6 %).
+// Kernels that call it in hot loops (general classes: position solver, TOI of polygons) define BLCD_SINCOS_INLINE - out of
+// line cost them 5-12 %.
 #if defined(BLCD_SINCOS_INLINE)
 #define BLCD_SINCOS_ATTR inline
 #else
 #define BLCD_SINCOS_ATTR __attribute__((noinline))
 #endif
 BLCD_HD static BLCD_SINCOS_ATTR void blcd_sincosf(float y, float* sinp, float* cosp) {
-  double x = y;
-  if (abstop12(y) < 0x3f4u) {          // |y| < 0x1.921FB6p-1f's top-12 class
-    if (abstop12(y) < 0x398u) {        // |y| < 2^-12
-      *sinp = y;
-      *cosp = 1.0f;
-      return;
+  const double kPio4 = 0x1.921fb54442d18p-1, kPio2 = 0x1.921fb54442d18p+0;
+  const double theta = y;
+  const double a = theta < 0.0 ? -theta : theta;
+  if (a < kPio4) {
+    const double t2 = theta * theta;
+    if (a >= 0x1p-5) {
+      *sinp = (float)sc_sin_poly(theta, t2);
+      *cosp = (float)sc_cos_poly(t2);
+    } else if (a >= 0x1p-27) {
+      *sinp = (float)(theta + theta * t2 * (-0x1.555555543d49dp-3 + t2 * 0x1.110f475cec8c5p-7));
+      *cosp = (float)(1.0 + t2 * (-0x1.fffffff5cc6fdp-2 + t2 * 0x1.55514b178dac5p-5));
+    } else {
+      *sinp = theta != 0.0 ? (float)(theta - theta * 0x1p-50) : y;
+      *cosp = (float)(1.0 - a);
     }
-    sincos_poly(x, x * x, sinp, cosp);
     return;
   }
-  int n;
-  int sign = 0;
-  if (abstop12(y) < 0x42fu) {          // |y| < 120
-    double r = x * 0x1.45F306DC9C883p+23;
-    n = ((int32_t)r + 0x800000) >> 24;
-    x = x - n * 0x1.921FB54442D18p0;
-  } else if (abstop12(y) < 0x7f8u) {   // finite
-    const uint32_t inv_pio4[24] = {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44,
-                                   0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
-                                   0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62,
-                                   0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
-    uint32_t xi = asuint(y);
-    sign = (int)(xi >> 31);
-    const uint32_t* arr = &inv_pio4[(xi >> 26) & 15];
-    int shift = (xi >> 23) & 7;
-    uint64_t nn, res0, res1, res2;
-    xi = (xi & 0xffffff) | 0x800000;
-    xi <<= shift;
-    res0 = xi * arr[0];
-    res1 = (uint64_t)xi * arr[4];
-    res2 = (uint64_t)xi * arr[8];
-    res0 = (res2 >> 32) | (res0 << 32);
-    res0 += res1;
-    nn = (res0 + (1ULL << 61)) >> 62;
-    res0 -= nn << 62;
-    x = (double)(int64_t)res0;
-    n = (int)nn;
-    x = x * 0x1.921FB54442D18p-62;
-  } else {
+  if (!(a < 0x1p+23)) {
     *sinp = *cosp = y - y;
     return;
   }
-  float sv, cv;
-  sincos_poly(x, x * x, &sv, &cv);
-  int q = n + sign;                    // quadrant used for the signs
-  // sign[q & 3] = {+,-,-,+} multiplies x (odd sine polynomial => flips sv; cosine polynomial even => unchanged)
-  if (((q & 3) == 1) || ((q & 3) == 2)) sv = -sv;
-  if (q & 2) cv = -cv;                 // second table = negated cosine polynomial
-  if (n & 1) {                         // odd quadrant: swap
-    *sinp = cv;
-    *cosp = sv;
-  } else {
-    *sinp = sv;
-    *cosp = cv;
-  }
+  const unsigned n = (unsigned)(a * 0x1.45f306dc9c883p+0) + 1u;     // |y| * 4/pi, +1
+  const double k = (double)(n >> 1);
+  double t;
+  if (a < 9 * kPio4) t = a - k * kPio2;                              // pio2_table[n / 2]
+  else t = (a - k * 0x1.921fb544p+0) - k * 0x1.0b4611a626332p-34;   // PI_2_hi, PI_2_lo
+  const double t2 = t * t;
+  const double sp = sc_sin_poly(t, t2), cp = sc_cos_poly(t2);
+  // sinf: polynomial by (n & 2), sign by ((n >> 2) & 1) ^ signbit; cosf: the same with n + 2 and no signbit
+  const unsigned m = n + 2u;
+  const double sv = (n & 2u) ? cp : sp, cv = (m & 2u) ? cp : sp;
+  const bool sneg = (((n >> 2) & 1u) != 0u) != (y < 0.0f), cneg = ((m >> 2) & 1u) != 0u;
+  *sinp = (float)(sneg ? -sv : sv);
+  *cosp = (float)(cneg ? -cv : cv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,8 +297,8 @@ struct Sweep {
   }
   BLCD_HD void Advance(float alpha) {
     float beta = (alpha - alpha0) / (1.0f - alpha0);
-    c0 += beta * (c - c0);
-    a0 += beta * (a - a0);
+    c0 = (1.0f - beta) * c0 + beta * c;      // Box2D 2.3.0 form (>= 2.3.1 writes c0 += beta * (c - c0))
+    a0 = (1.0f - beta) * a0 + beta * a;
     alpha0 = alpha;
   }
   BLCD_HD void Normalize() {

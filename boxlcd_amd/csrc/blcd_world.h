@@ -1398,8 +1398,8 @@ struct Env {
         a0[i] = a[i];
         v_ += h * (1.0f * gravity + invMass[i] * V2(0.0f, 0.0f));
         w_ += h * invI[i] * 0.0f;
-        v_ *= 1.0f / (1.0f + h * S->bodies[i].linearDamping);
-        w_ *= 1.0f / (1.0f + h * S->bodies[i].angularDamping);
+        v_ *= Clamp(1.0f - h * S->bodies[i].linearDamping, 0.0f, 1.0f);    // Box2D 2.3.0 (first-order; >= 2.3.1 is Pade)
+        w_ *= Clamp(1.0f - h * S->bodies[i].angularDamping, 0.0f, 1.0f);
       }
       R.pos[i].c = c[i];
       R.pos[i].a = a[i];
@@ -1581,8 +1581,8 @@ struct Env {
       a0[i] = a[i];
       v_ += h * (1.0f * gravity + invMass[i] * V2(0.0f, 0.0f));
       w_ += h * invI[i] * 0.0f;
-      v_ *= 1.0f / (1.0f + h * S->bodies[i].linearDamping);
-      w_ *= 1.0f / (1.0f + h * S->bodies[i].angularDamping);
+      v_ *= Clamp(1.0f - h * S->bodies[i].linearDamping, 0.0f, 1.0f);      // Box2D 2.3.0 (first-order; >= 2.3.1 is Pade)
+      w_ *= Clamp(1.0f - h * S->bodies[i].angularDamping, 0.0f, 1.0f);
       pc[i] = c[i];
       pa[i] = a[i];
       pv[i] = v_;

@@ -161,7 +161,7 @@ static inline float b2o_sinf_g227(float x) {
     }
     return theta != 0.0 ? (float)(theta - theta * SMALL) : x;
   }
-  if (!(abstheta < 0x1p+23)) return (float)sin(theta);   // never reached by body angles
+  if (!(abstheta < 0x1p+23)) return x - x;   // outside the restated domain (body angles never reach it)
   unsigned n;
   double t = reduce(abstheta, &n);
   return reduced_sin(t, n, x < 0.0f ? 1u : 0u);
@@ -178,7 +178,7 @@ static inline float b2o_cosf_g227(float x) {
     }
     return (float)(1.0 - abstheta);
   }
-  if (!(abstheta < 0x1p+23)) return (float)cos(theta);
+  if (!(abstheta < 0x1p+23)) return x - x;
   unsigned n;
   double t = reduce(abstheta, &n);
   return reduced_cos(t, n);

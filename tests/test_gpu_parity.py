@@ -62,43 +62,30 @@ def test_render_poses_equals_oracle_and_pillow(name, variant):
   h.close()
 
 
-def test_gif_sequences_on_device():
-  """The reference's published LCD sequences (ball, box, ball-ball, box-ball, box-box), reproduced by the HIP path itself."""
-  from test_oracle_physics import BOX_AND_BALL_START, CUBES_START
-  gifs = np.load('tests/golden/gif_lcd_frames.npz')
-  for name, key, pose, sel, T in [('Object2', 'Object2', BOX_AND_BALL_START, [1, 0], 50), ('Object2', 'Object2_cubes', CUBES_START, [1, 1], 50)] + [
-      (n_, k_, p_, None, t_) for n_, k_, p_, t_ in [('Dropbox', 'Dropbox', [[1.66, 4.015, 1.315]], 26), ('Bounce', 'Bounce', [[1.55, 4.17, 0.0]], 50),
-                             ('Bounce2', 'Bounce2', [[1.60323, 4.17499, 0.0], [2.47265, 3.01481, 0.0]], 50),
-                             ('Object2', 'Object2_circles', [[3.7294, 2.56002, 0.0], [3.58992, 0.70644, 0.0]], 50)]]:
-    env = getattr(B.envs, name)()
-    h = Handle(env.scene.desc, 1, 0)
-    h.reset(None, np.array([pose], np.float32), None if sel is None else np.array([sel], np.int32))
-    lcd = np.zeros((T, 1, 16, 16), np.uint8)
-    h.rollout(None, T, lcd_out=lcd)
-    exp = np.unpackbits(gifs[key], axis=-1)[:, :, :16]
-    assert (lcd[:, 0] == exp).all(), key
-    h.close()
-
-
-def test_robot_gif_sequences_on_device():
-  """Robot recordings (revolute joints, motors, limits; known action tape, see tests/test_oracle_physics.py) replayed by the
-  HIP path with the recording-era raster rule: Urchin 100/100 and UrchinBall 150/150 frames identical, Luxo all but the
-  documented 6 px."""
-  import json
-  gifs = np.load('tests/golden/gif_lcd_frames.npz')
-  starts = json.load(open('tests/golden/gif_robot_starts.json'))
-  for name, budget in [('Urchin', 0), ('UrchinBall', 0), ('Luxo', 6), ('LuxoBall', 7)]:
-    env = getattr(B.envs, name)(raster_variant=2)
-    W = env.scene.desc.lcd_w
-    exp = np.unpackbits(gifs[name], axis=-1)[:, :, :W]
+def test_recordings_replayed_on_device_from_recorder_inputs():
+  """The reference's published recordings reproduced by the HIP path itself from the recorder's own inputs (env.seed(S) reset
+  sample + RandomState(A) action tape, tests/replay.py; no fitted pose): every LCD frame of the eight recordings the oracle
+  reproduces exactly, and the same frame counts as the oracle on the four open ones (tests/test_oracle_replay.py)."""
+  import replay as R
+  for gif, (cls, force_sel, seed, aseed) in R.GIFS.items():
+    env = getattr(B.envs, cls)(raster_variant=2)
+    d = env.scene.desc
+    _, exp = R.fixtures(gif)
     T = len(exp)
-    rs = np.random.RandomState(4)
+    P, sel = R.recorder_start(env, seed)
+    if force_sel is not None:
+      sel = np.array(force_sel, np.int32)
+    rs = np.random.RandomState(aseed)
     acts = np.stack([rs.uniform(-1, 1, env.act_size) for _ in range(T)]).astype(np.float32)[:, None, :]
-    h = Handle(env.scene.desc, 1, 0)
-    h.reset(None, np.array([starts[name]], np.float32), None)
-    lcd = np.zeros((T, 1, 16, W), np.uint8)
+    h = Handle(d, 1, 0)
+    h.reset(None, P[None].astype(np.float32), np.asarray(sel, np.int32)[None])
+    lcd = np.zeros((T, 1, d.lcd_h, d.lcd_w), np.uint8)
     h.rollout(acts, T, lcd_out=lcd)
-    assert int((lcd[:, 0] != exp).sum()) <= budget, name
+    bad = [int((lcd[t, 0] != exp[t]).sum()) for t in range(T)]
+    obad, _ = R.replay(gif, pyb2o, want_rgb=False)
+    assert bad == obad, gif                                   # device == oracle, frame by frame
+    if gif in ('Dropbox', 'Bounce', 'Bounce2', 'Object2', 'Object2_circles', 'Object2_cubes', 'UrchinBall', 'UrchinCube'):
+      assert sum(bad) == 0, (gif, R.summary(bad))
     h.close()
 
 
