@@ -1,19 +1,24 @@
 #!/usr/bin/env python
 """bench.py — env-steps/s of the batched boxLCD hot path (step + obs + LCD render) on N MI355X GPUs of one node.
 
-Workload at N=1 = BASELINE.json configs[1]: envs.Bounce() 16x16, 100 000 parallel envs, 200 env-steps from reset.
-One bench "step" = one such rollout (reset -> 200 x [step_kernel + obs/raster kernel], per-step LCD and observation
-tensors written to HBM).  Inputs (initial poses, action tape) are resident in HBM before the timed region.
-Weak scaling: every rank (one process per GPU) owns `envs` environments; the only collective is an all-gather of the
-final frame/observation tensors per rollout (RCCL), as the reference's collectors concatenate per-env results.
+Workload at N=1 = BASELINE.json configs[1]: envs.Bounce() 16x16, 100 000 parallel envs, 200-env-step rollouts from reset.
+One bench "step" = `--rollouts-per-step` (default 20) such rollouts = 4 000 env-steps of every environment (reset -> 200 x
+[world steps + obs + LCD raster], per-step LCD and observation tensors written to HBM), so that the driver's `--steps 20`
+times ~5 s of GPU work.  Inputs (initial poses, action tape) are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description): metric/value/unit, roofline block
-(HBM, algorithmic bytes per env-step from SURVEY.md §8d x envs per launch / average step_kernel launch time measured with
-hipEvents on the handle's stream) and cpu_baseline block (CPU oracle, all host cores, bounded sample).
+Weak scaling (`--gpus N`, one process per GPU, launched by torchrun): every rank owns `--envs` environments and steps them
+with no data-path collective; after every fused chunk (20 env-steps) the chunk's FULL result tensors `lcd[Tc, N, 16, W]`
+and `full_state[Tc, N, obs]` are all-gathered over RCCL on a side stream, overlapped with the next chunk.
+
+Prints ONE JSON line on rank 0: metric/value/unit, `roofline` (HBM; algorithmic bytes per env-step from SURVEY.md §8d x envs
+x env-steps per launch / mean step_kernel launch time from hipEvents on the handle's stream), `cpu_baseline` (the CPU oracle
+on the host cores over a bounded sample), `parity` (BASELINE's second metric on a sample of the timed batch) and `configs`
+(the other single-GPU BASELINE workloads incl. north_star's Dropbox-100k, each with its own roofline block).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,11 +27,14 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES = {'Dropbox': 564, 'Bounce': 564, 'Object2': 924, 'Urchin': 1836, 'LuxoBall': 2236}
 HBM_PEAK_GBS = 8000.0                                                                            # MI355X_MICROARCH.md
+RASTER_NAMES = {0: 'pillow-9.0.x (inferred)', 1: 'pillow-12.2 (goldens)', 2: 'recording era (GIF frames)'}
+# HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes (separate --pmc runs) of the default workload;
+# only quoted when the run uses that workload with default knobs.
+TRAFFIC_PROFILE = 'profiles/r01_final4_bounce100k_pmc.json'
 
 
 def cpu_baseline(env_name, T, target_s=12.0):
-  """CPU oracle ("port") on all host cores, bounded sample of the same workload (same sampler, same action tape law)."""
-  import numpy as np
+  """CPU oracle ("port") on the host cores, bounded sample of the same workload (same sampler, same action tape law)."""
   import boxlcd_amd as B
   from oracle import pyb2o
   try:
@@ -62,106 +70,175 @@ def parity_sample(desc, poses, sel, acts, T, gpu_state, gpu_lcd, idx, cores):
           'max_abs_pose_diff': float(np.abs(gpu_state[idx][:, :, :3] - ost[:, :, :3]).max())}
 
 
+class Workload:
+  """One env class x batch size on one GPU: resident inputs, output tensors, and the rollout loop."""
+
+  def __init__(self, env_name, N, T, local, dev, seed, chunk=20):
+    import torch
+    import boxlcd_amd as B
+    from boxlcd_amd._lib import Handle
+    self.name, self.N, self.T, self.chunk = env_name, N, T, chunk
+    self.venv = B.BatchedWorldEnv(env_name, N, seed=seed)
+    self.d = d = self.venv.scene.desc
+    self.h = Handle(d, N, local)
+    self.poses_np, self.sel_np = self.venv.sample_initial(N)
+    self.poses = torch.as_tensor(self.poses_np).to(dev)
+    self.sel = torch.as_tensor(self.sel_np).to(dev)
+    self.acts = torch.as_tensor(self.venv.sample_actions(T)).to(dev)                 # [T, N, act] resident in HBM
+    self.lcd = torch.empty((T, N, d.lcd_h, d.lcd_w), dtype=torch.uint8, device=dev)
+    self.obs = torch.empty((T, N, d.n_obs), dtype=torch.float32, device=dev)
+    self.kernel_ms, self.launches = 0.0, 0
+    self.stream = torch.cuda.ExternalStream(self.h.stream(), device=dev)
+    self.gatherer, self.gather_done = None, {}
+
+  def enable_gather(self, world):
+    from boxlcd_amd import dist as bdist
+    c = min(self.chunk, self.T)
+    self.gatherer = bdist.ChunkGatherer(world, [self.lcd[:c], self.obs[:c]])
+
+  def rollout(self):
+    h = self.h
+    h.reset(None, self.poses, self.sel)
+    if self.gatherer is None:
+      h.rollout(self.acts, self.T, self.lcd, self.obs)
+      ms, n = h.last_kernel_ms()
+      self.kernel_ms += ms
+      self.launches += n
+      return
+    for t0 in range(0, self.T, self.chunk):
+      t1 = min(self.T, t0 + self.chunk)
+      if t0 in self.gather_done:                      # the previous rollout's gather still reads this region
+        self.stream.wait_event(self.gather_done[t0])
+      h.rollout(self.acts[t0:t1], t1 - t0, self.lcd[t0:t1], self.obs[t0:t1])
+      ms, n = h.last_kernel_ms()
+      self.kernel_ms += ms
+      self.launches += n
+      if t1 - t0 == self.chunk:
+        self.gather_done[t0] = self.gatherer.gather([self.lcd[t0:t1], self.obs[t0:t1]], producer=self.stream)
+
+  def roofline(self, rollouts):
+    avg_launch_s = (self.kernel_ms / max(self.launches, 1)) / 1e3
+    steps_per_launch = self.T * rollouts / max(self.launches, 1)     # one launch advances N envs by this many env-steps
+    bpe = ALG_BYTES.get(self.name, 0)
+    achieved = bpe * self.N * steps_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': None, 'kernel': 'step_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
+            'env_steps_per_env_per_launch': steps_per_launch, 'alg_bytes_per_env_step': bpe,
+            'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'}
+
+  def close(self):
+    self.h.close()
+
+
+def time_rollouts(w, rollouts, warmup, bdist, torch):
+  for _ in range(warmup):
+    w.rollout()
+  if w.gatherer is not None:
+    w.gatherer.finish()
+  w.kernel_ms, w.launches = 0.0, 0
+  bdist.barrier(); torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(rollouts):
+    w.rollout()
+  if w.gatherer is not None:
+    w.gatherer.finish()
+  torch.cuda.synchronize(); bdist.barrier()
+  return bdist.max_over_ranks(time.perf_counter() - t0)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=3, help='timed rollouts (each = envs x rollout_len env-steps)')
-  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20, help='timed bench steps (each = --rollouts-per-step rollouts)')
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--rollouts-per-step', type=int, default=20, help='rollouts of --rollout-len env-steps per bench step')
   ap.add_argument('--env', default='Bounce')
   ap.add_argument('--envs', type=int, default=100000, help='environments per GPU')
   ap.add_argument('--rollout-len', type=int, default=200)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-configs', action='store_true', help='skip the extra single-GPU workloads of the `configs` block')
   args = ap.parse_args()
+
+  world_env = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.gpus > 1 and world_env == 1 and 'RANK' not in os.environ:
+    # not under torchrun: start one process per GPU BEFORE anything touches the GPU, and exit with the launcher's code
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', os.environ.get('MASTER_PORT', '29533'), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
   import numpy as np
   import torch
-  import boxlcd_amd as B
   from boxlcd_amd import dist as bdist
-  from boxlcd_amd._lib import Handle
 
   # BENCH_BACKEND=gloo BENCH_DEVICE=0: rehearse the N>1 path on a box with fewer GPUs than ranks (never used by the driver)
   rank, world, local = bdist.init_from_env(os.environ.get('BENCH_BACKEND'))
   if 'BENCH_DEVICE' in os.environ:
     local = int(os.environ['BENCH_DEVICE'])
   if world != args.gpus:
-    if rank == 0:
-      print(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
   if not torch.cuda.is_available():
     raise RuntimeError('bench.py needs a GPU: boxlcd_amd has no CPU path')
   torch.cuda.set_device(local)
   dev = torch.device('cuda', local)
   N, T = args.envs, args.rollout_len
+  overrides = {k: v for k, v in os.environ.items() if k.startswith('BLCD_') or k.startswith('BOXLCD_')}
 
-  venv = B.BatchedWorldEnv(args.env, N, seed=1000 + rank)
-  d = venv.scene.desc
-  h = Handle(d, N, local)
-  poses_np, sel_np = venv.sample_initial(N)
-  poses = torch.as_tensor(poses_np).to(dev)
-  sel = torch.as_tensor(sel_np).to(dev)
-  acts = torch.as_tensor(venv.sample_actions(T)).to(dev)                   # [T, N, act] resident in HBM
-  lcd = torch.empty((T, N, d.lcd_h, d.lcd_w), dtype=torch.uint8, device=dev)
-  obs = torch.empty((T, N, d.n_obs), dtype=torch.float32, device=dev)
+  w = Workload(args.env, N, T, local, dev, seed=1000 + rank)
+  d = w.d
+  if world > 1:
+    w.enable_gather(world)
   torch.cuda.synchronize()
+  rollouts = args.steps * args.rollouts_per_step
+  dt = time_rollouts(w, rollouts, args.warmup * args.rollouts_per_step, bdist, torch)
 
-  kernel_ms, launches = [], []
-
-  def one_rollout():
-    h.reset(None, poses, sel)
-    h.rollout(acts, T, lcd, obs)
-    ms, n = h.last_kernel_ms()
-    kernel_ms.append(ms)
-    launches.append(n)
-    if world > 1:                                                            # concatenate the rollout's final tensors
-      bdist.all_gather_shards(lcd[-1], N * world)
-      bdist.all_gather_shards(obs[-1], N * world)
-
-  for _ in range(args.warmup):
-    one_rollout()
-  kernel_ms.clear(); launches.clear()
-  bdist.barrier(); torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    one_rollout()
-  torch.cuda.synchronize(); bdist.barrier()
-  dt = bdist.max_over_ranks(time.perf_counter() - t0)
-
-  faults = int((h.faults() != 0).sum())
-  awake_frac = float(h.get_poses()[:, :, 3].mean())
+  faults = int((w.h.faults() != 0).sum())
+  awake_frac = float(w.h.get_poses()[:, :, 3].mean())
   if rank == 0:
-    total_env_steps = float(args.steps) * T * N * world
-    avg_launch_s = (sum(kernel_ms) / max(sum(launches), 1)) / 1e3
-    # one launch advances N envs by (T / launches-per-rollout) env-steps (fused rollout chunks)
-    steps_per_launch = T * args.steps / max(sum(launches), 1)
-    bytes_per_launch = ALG_BYTES.get(args.env, 0) * N * steps_per_launch
-    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    traffic = None   # HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes of this same command
-    try:
-      prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_final4_bounce100k_pmc.json')))
-      if args.env == 'Bounce' and N == 100000 and T == 200:
+    total_env_steps = float(rollouts) * T * N * world
+    roof = w.roofline(rollouts)
+    default_knobs = args.env == 'Bounce' and N == 100000 and T == 200 and not overrides
+    if default_knobs:
+      try:
+        prof = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
         k = [x for x in prof if 'step_kernel' in x][0]
-        traffic = (prof[k]['FETCH_SIZE']['mean'] + prof[k]['WRITE_SIZE']['mean']) * 1024.0
-    except Exception:
-      traffic = None
+        roof['traffic'] = (prof[k]['FETCH_SIZE']['mean'] + prof[k]['WRITE_SIZE']['mean']) * 1024.0
+        roof['traffic_source'] = f'{TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (KB -> B) per step_kernel launch of this same command; profile-derived, not measured in this run'
+      except Exception:
+        roof['traffic'] = None
     out = {
         'metric': 'env_steps_per_sec', 'value': total_env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'envs.{args.env}() {d.lcd_h}x{d.lcd_w}, {N} envs/GPU, {T} env-steps per rollout from reset, '
-                               'U(-1,1) actions, obs + LCD rendered every step', 'envs_per_gpu': N, 'rollout_len': T,
-                   'parallelism': f'env-sharded x{world}', 'raster_variant': 'legacy', 'faulted_envs': faults,
-                   'awake_fraction_at_end': awake_frac},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': 'profiles/r01_final4_bounce100k_pmc.json (FETCH_SIZE + WRITE_SIZE, KB -> B, per launch)', 'kernel': 'step_kernel',
-                     'avg_launch_ms': avg_launch_s * 1e3, 'env_steps_per_env_per_launch': steps_per_launch, 'alg_bytes_per_env_step': ALG_BYTES.get(args.env, 0),
-                     'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'},
+        'config': {'workload': f'envs.{args.env}() {d.lcd_h}x{d.lcd_w}, {N} envs/GPU, one step = {args.rollouts_per_step} rollouts of {T} env-steps '
+                               'from reset, U(-1,1) actions, obs + LCD rendered every env-step', 'envs_per_gpu': N, 'rollout_len': T,
+                   'rollouts_per_step': args.rollouts_per_step, 'parallelism': f'env-sharded x{world}',
+                   'collective': None if world == 1 else f'all-gather of every chunk\'s lcd[{w.chunk},{N},{d.lcd_h},{d.lcd_w}] u8 + full_state[{w.chunk},{N},{d.n_obs}] f32 on a side stream',
+                   'raster_variant': RASTER_NAMES.get(w.venv.raster_variant, str(w.venv.raster_variant)), 'overrides': overrides,
+                   'faulted_envs': faults, 'awake_fraction_at_end': awake_frac},
+        'roofline': roof,
     }
-    if not args.no_cpu_baseline and world == 1:
+    if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args.env, T)
       idx = np.random.RandomState(0).choice(N, min(N, 1024), replace=False)
-      out['parity'] = parity_sample(d, poses_np, sel_np, acts.cpu().numpy(), T, h.debug_dump()[0], lcd[-1].cpu().numpy(), idx,
+      out['parity'] = parity_sample(d, w.poses_np, w.sel_np, w.acts.cpu().numpy(), T, w.h.debug_dump()[0], w.lcd[-1].cpu().numpy(), idx,
                                     out['cpu_baseline']['cores'])
+  w.close()
+  del w
+  torch.cuda.empty_cache()
+  if rank == 0 and world == 1 and not args.no_configs and args.env == 'Bounce':
+    # the other single-GPU BASELINE workloads, driver-run: north_star's Dropbox-100k target and configs[2] Urchin-50k
+    cfgs = {}
+    for name, n_envs, rolls in (('Dropbox', 100000, 20), ('Urchin', 50000, 3)):
+      ww = Workload(name, n_envs, T, local, dev, seed=1000)
+      sec = time_rollouts(ww, rolls, 1, bdist, torch)
+      cfgs[f'{name}-{n_envs}'] = {'value': rolls * T * n_envs / sec, 'unit': 'env-steps/s', 'rollouts': rolls, 'seconds': sec,
+                                  'faulted_envs': int((ww.h.faults() != 0).sum()), 'roofline': ww.roofline(rolls)}
+      ww.close()
+      del ww
+      torch.cuda.empty_cache()
+    out['configs'] = cfgs
+  if rank == 0:
     print(json.dumps(out))
-  h.close()
   if world > 1:
     torch.distributed.destroy_process_group()
 

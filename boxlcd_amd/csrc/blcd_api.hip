@@ -427,7 +427,11 @@ static int lower_scene(const blcd_scene_desc& d, DevScene* S) {
   S->velIters = d.vel_iters;
   S->posIters = d.pos_iters;
   S->nShapes = d.n_shapes;
+#ifdef BLCD_ABLATION
   S->dbgSkip = getenv("BLCD_DEBUG_SKIP") ? atoi(getenv("BLCD_DEBUG_SKIP")) : 0;
+#else
+  S->dbgSkip = 0;
+#endif
   // walls: boxLCD/world_env.py:311-314 — bottom, left, right, top
   float W = d.world_w, H = d.world_h;
   Vec2 ev[4][2] = {{V2(0, 0), V2(W, 0)}, {V2(0, 0), V2(0, H)}, {V2(W, 0), V2(W, H)}, {V2(0, H), V2(W, H)}};

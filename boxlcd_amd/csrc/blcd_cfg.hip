@@ -35,8 +35,10 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   Env<NB, NJ, NP, SH> env;
   env.load(S, st, N, slot);
   env.profOn = waveTimes != nullptr;
-  if (S->dbgSkip & 8) {
-  } else if (nEnvSteps > 0) {
+#ifdef BLCD_ABLATION
+  if (S->dbgSkip & 8) nEnvSteps = nWorldSteps = 0;
+#endif
+  if (nEnvSteps > 0) {
     // Fused rollout: this wave advances its environments through all nEnvSteps on its own (no grid-wide barrier between
     // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.
     const size_t lcdRow = (size_t)S->lcdH * S->lcdW;

@@ -68,7 +68,7 @@ struct DevScene {
   float dt;
   int substeps, velIters, posIters;
   int nShapes;
-  int dbgSkip;  // timing-only ablation (BLCD_DEBUG_SKIP): 1 collide, 2 solve, 4 TOI, 8 everything  (results are wrong when set)
+  int dbgSkip;  // only read by -DBLCD_ABLATION builds (BLCD_DEBUG_SKIP: 1 collide, 2 solve, 4 TOI, 8 everything; results are wrong when set)
   Shape wallShape[4];
   AABB wallFat[4];
   Shape shapes[24];
@@ -2001,10 +2001,12 @@ struct Env {
     float dt = S->dt;
     float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
     float dtRatio = inv_dt0 * dt;
-#ifdef BLCD_CT_SKIP
+#if defined(BLCD_CT_SKIP)
     const int skip = BLCD_CT_SKIP;   // compile-time phase removal: register-pressure experiments only
+#elif defined(BLCD_ABLATION)
+    const int skip = S->dbgSkip;     // run-time phase removal (BLCD_DEBUG_SKIP): ablation builds only, never the shipped library
 #else
-    const int skip = S->dbgSkip;
+    constexpr int skip = 0;
 #endif
     unsigned long long c0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
     if (!(skip & 1)) collide();

@@ -51,6 +51,51 @@ def all_gather_shards(t, n_total, dim=0):
   return torch.cat(parts, 0).movedim(0, dim)
 
 
+class ChunkGatherer:
+  """All-gather of one rollout chunk's result tensors (`lcd[Tc, N, H, W]`, `full_state[Tc, N, obs]`) into
+  preallocated `[world, Tc, N, ...]` buffers, on a side stream so that the next chunk's stepping overlaps the transfer.
+
+  Equal shards (the bench's weak-scaling layout) go through `all_gather_into_tensor` straight into the destination - no
+  pad, no concatenate.  Destination buffers are double-buffered; collectives are ordered by the side stream, so a buffer is
+  only rewritten after the gather that last filled it has finished.  `producer` is the stream the chunk was written on
+  (the handle's stream); the returned event marks the end of the gather: make the producer wait on it before it rewrites
+  the source region (`producer.wait_event(ev)`)."""
+
+  def __init__(self, world, templates, nbuf=2):
+    import torch
+    self.world = world
+    self.cuda = templates[0].is_cuda
+    self.bufs = [[torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in templates] for _ in range(nbuf)]
+    self.k = 0
+    self.stream = torch.cuda.Stream(device=templates[0].device) if self.cuda else None
+
+  def gather(self, srcs, producer=None):
+    import torch
+    import torch.distributed as dist
+    dst = self.bufs[self.k % len(self.bufs)]
+    self.k += 1
+    if not self.cuda:                       # gloo rehearsal on CPU: synchronous
+      for d, s in zip(dst, srcs):
+        dist.all_gather(list(d.unbind(0)), s.contiguous())
+      return None
+    ready = torch.cuda.Event()
+    ready.record(producer if producer is not None else torch.cuda.current_stream())
+    with torch.cuda.stream(self.stream):
+      self.stream.wait_event(ready)
+      for d, s in zip(dst, srcs):
+        dist.all_gather_into_tensor(d.flatten(0, 1), s)   # [world*Tc, N, ...] = concatenation along dim 0 (NCCL and gloo)
+      done = torch.cuda.Event()
+      done.record(self.stream)
+    return done
+
+  def last(self):
+    return self.bufs[(self.k - 1) % len(self.bufs)]
+
+  def finish(self):
+    if self.cuda:
+      self.stream.synchronize()
+
+
 def max_over_ranks(x):
   import torch
   import torch.distributed as dist

@@ -20,10 +20,21 @@ def _worker(rank, world, port, n_total, q):
   obs = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1).repeat(1, 4)
   full_lcd = bdist.all_gather_shards(lcd, n_total)
   full_obs = bdist.all_gather_shards(obs, n_total)
+  # per-chunk gather of the FULL chunk tensors [Tc, N, ...] (what bench.py --gpus N moves), equal shards, double-buffered
+  Tc, n_eq = 3, 5
+  g = bdist.ChunkGatherer(w, [torch.empty((Tc, n_eq, 16, 16), dtype=torch.uint8), torch.empty((Tc, n_eq, 4))])
+  chunk_ok = True
+  for chunk in range(3):
+    cl = torch.full((Tc, n_eq, 16, 16), 10 * chunk + r, dtype=torch.uint8)
+    co = torch.full((Tc, n_eq, 4), float(10 * chunk + r))
+    g.gather([cl, co])
+    gl, go = g.last()
+    chunk_ok = chunk_ok and gl.shape == (w, Tc, n_eq, 16, 16) and all((gl[k] == 10 * chunk + k).all() and (go[k] == 10 * chunk + k).all() for k in range(w))
+  g.finish()
   t = bdist.max_over_ranks(1.0 + rank)
   bdist.barrier()
   ok = full_lcd.shape == (n_total, 16, 16) and (full_lcd[:, 0, 0].numpy() == np.arange(n_total)).all() and \
-      (full_obs[:, 0].numpy() == np.arange(n_total)).all() and t == float(world)
+      (full_obs[:, 0].numpy() == np.arange(n_total)).all() and t == float(world) and bool(chunk_ok)
   q.put((rank, bool(ok)))
   torch.distributed.destroy_process_group()
 
