@@ -26,6 +26,8 @@ SYMBOLS = {
     'blcd_goal_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'blcd_get_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'blcd_render_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'blcd_set_ellipse_rgb_lut': (C.c_int, [C.c_void_p, C.c_int32]),
+    'blcd_render_poses_ex': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     'blcd_get_poses': (C.c_int, [C.c_void_p, C.c_void_p]),
     'blcd_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
     'blcd_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -57,6 +59,15 @@ def load():
     fn = getattr(lib, name)  # AttributeError if the library does not export it
     fn.restype, fn.argtypes = res, args
   _lib = lib
+  # Pillow's ellipse fill/outline span table (DATA, tools/gen_ellipse_rgb_lut.py) for lcd_render(width, height, 'RGB')
+  lut = np.fromfile(os.path.join(os.path.dirname(LIB_PATH), 'ellipse_rgb_lut.bin'), np.uint8)
+  amax = 0
+  while (amax + 1) * 5 * (amax + 3) * 6 < lut.size:
+    amax += 1
+  if (amax + 1) * 5 * (amax + 3) * 6 != lut.size:
+    raise RuntimeError('ellipse_rgb_lut.bin has an unexpected size')
+  if lib.blcd_set_ellipse_rgb_lut(lut.ctypes.data_as(C.c_void_p), amax) != 0:
+    raise RuntimeError('blcd_set_ellipse_rgb_lut failed')
   return lib
 
 
@@ -194,6 +205,18 @@ class Handle:
       shape_sel = np.ascontiguousarray(shape_sel, dtype=np.int32)
     img = np.zeros((m, self.h, self.w), np.uint8)
     _check(self.lib.blcd_render_poses(self._h, _ptr(poses), _ptr(shape_sel), m, _ptr(img)))
+    return img
+
+  def render_poses_ex(self, poses, shape_sel, width, height, mode='1'):
+    """lcd_render(width, height, lcd_mode) for m pose sets: '1' -> uint8 [m, H, W]; 'RGB' -> uint8 [m, H, W, 3]"""
+    poses = np.ascontiguousarray(poses, dtype=np.float32)
+    m = poses.shape[0]
+    assert poses.shape == (m, self.nb, 3)
+    if shape_sel is not None:
+      shape_sel = np.ascontiguousarray(shape_sel, dtype=np.int32)
+    rgb = mode.upper() == 'RGB'
+    img = np.zeros((m, height, width, 3) if rgb else (m, height, width), np.uint8)
+    _check(self.lib.blcd_render_poses_ex(self._h, _ptr(poses), _ptr(shape_sel), m, int(width), int(height), int(rgb), _ptr(img)))
     return img
 
   def get_poses(self):

@@ -13,6 +13,9 @@
 #include "../../include/boxlcd.h"
 #include "blcd_emit.h"
 #include "blcd_cfg_launch.h"
+#include "blcd_render_ex.h"
+#include <vector>
+#include <mutex>
 
 using namespace blcd;
 
@@ -464,6 +467,7 @@ static int lower_scene(const blcd_scene_desc& d, DevScene* S) {
     B.cat = bd.category_bits;
     B.mask = bd.mask_bits;
     B.nJoints = 0;
+    S->bodyKind[i] = bd.kind;
   }
   for (int j = 0; j < d.n_joints; ++j) {
     const blcd_joint_def& jd = d.joints[j];
@@ -561,6 +565,9 @@ struct blcd_handle_s {
   int lastLaunches = 0;
   // staging
   void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint8_t* dLut = nullptr;   // Pillow's ellipse span table for blcd_render_poses_ex (uploaded on first use)
+  int lutAmax = -1;
+  int* dErr = nullptr;
   size_t stageBytes[4] = {0, 0, 0, 0};
   int cfg = -1;
 };
@@ -881,6 +888,8 @@ int blcd_destroy(blcd_handle h) {
     if (h->stage[k]) (void)hipFree(h->stage[k]);
   for (void* q : {(void*)h->dGoal, (void*)h->goalFs, (void*)h->goalLast, (void*)h->goalObs, (void*)h->goalLcd, (void*)h->goalCurLcd})
     if (q) (void)hipFree(q);
+  if (h->dLut) (void)hipFree(h->dLut);
+  if (h->dErr) (void)hipFree(h->dErr);
   if (h->st) (void)hipFree(h->st);
   if (h->st2) (void)hipFree(h->st2);
   if (h->eid) (void)hipFree(h->eid);
@@ -1082,6 +1091,56 @@ static int goal_launch(blcd_handle h, const int* dIdx, int n, int seedOnly, doub
   hipLaunchKernelGGL(goal_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->dGoal, h->N, h->hostScene.nobs, lcdBytes, dIdx,
                      n, seedOnly, h->goalObs, h->goalCurLcd, h->goalFs, h->goalLcd, h->goalLast, dRew, dDone, dDelta);
   HIPCHK(hipGetLastError());
+  return BLCD_OK;
+}
+
+// ---- lcd_render(width, height, lcd_mode) --------------------------------------------------------------------------
+static std::vector<uint8_t> g_lutHost;   // process-wide: Pillow's ellipse fill/outline span table (DATA, boxlcd_amd/ellipse_rgb_lut.bin)
+static int g_lutAmax = -1;
+static std::mutex g_lutMutex;
+
+int blcd_set_ellipse_rgb_lut(const uint8_t* lut, int32_t amax) {
+  if (!lut || amax < 0 || amax > 254) return fail(BLCD_ERR_INVALID, "blcd_set_ellipse_rgb_lut: bad arguments");
+  std::lock_guard<std::mutex> lock(g_lutMutex);
+  g_lutHost.assign(lut, lut + (size_t)(amax + 1) * 5 * (amax + 3) * 6);
+  g_lutAmax = amax;
+  return BLCD_OK;
+}
+
+int blcd_render_poses_ex(blcd_handle h, const float* poses, const int32_t* shape_sel, int32_t m, int32_t width, int32_t height,
+                         int32_t mode, uint8_t* out) {
+  if (!h || !poses || !out || m < 1 || width < 1 || height < 1 || width > 4096 || height > 4096 || (mode != 0 && mode != 1))
+    return fail(BLCD_ERR_INVALID, "blcd_render_poses_ex: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  {
+    std::lock_guard<std::mutex> lock(g_lutMutex);
+    if (g_lutAmax < 0) return fail(BLCD_ERR_INVALID, "blcd_render_poses_ex: call blcd_set_ellipse_rgb_lut first (boxlcd_amd/ellipse_rgb_lut.bin)");
+    if (h->lutAmax != g_lutAmax) {
+      if (h->dLut) (void)hipFree(h->dLut);
+      h->dLut = nullptr;
+      HIPCHK(hipMalloc((void**)&h->dLut, g_lutHost.size()));
+      HIPCHK(hipMemcpy(h->dLut, g_lutHost.data(), g_lutHost.size(), hipMemcpyHostToDevice));
+      h->lutAmax = g_lutAmax;
+    }
+  }
+  if (!h->dErr) HIPCHK(hipMalloc((void**)&h->dErr, sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
+  const int nb = h->hostScene.nb;
+  const size_t bytes = (size_t)m * height * width * (mode ? 3 : 1);
+  const void *dPoses, *dSel;
+  void* dOut;
+  int rc;
+  if ((rc = in_ptr(h, 0, poses, (size_t)m * nb * 3 * sizeof(float), &dPoses))) return rc;
+  if ((rc = in_ptr(h, 1, shape_sel, (size_t)m * nb * sizeof(int32_t), &dSel))) return rc;
+  if ((rc = out_ptr(h, 2, out, bytes, &dOut))) return rc;
+  hipLaunchKernelGGL(render_ex_kernel, dim3((unsigned)m), dim3(64), 0, h->stream, h->dScene, m, (const float*)dPoses, (const int*)dSel,
+                     width, height, mode, (const uint8_t*)h->dLut, h->lutAmax, (uint8_t*)dOut, h->dErr);
+  HIPCHK(hipGetLastError());
+  int err = 0;
+  HIPCHK(hipMemcpyAsync(&err, h->dErr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if ((rc = out_done(h, 2, out, bytes, dOut))) return rc;
+  if (err) return fail(BLCD_ERR_INVALID, "blcd_render_poses_ex: a circle's bounding box is outside Pillow's span table (too large a canvas)");
   return BLCD_OK;
 }
 

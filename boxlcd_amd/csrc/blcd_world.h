@@ -73,6 +73,7 @@ struct DevScene {
   AABB wallFat[4];
   Shape shapes[24];
   DevBody bodies[20];
+  int bodyKind[20];   // 0 object, 1 robot root, 2 robot link: colours of the RGB render only
   DevJoint joints[20];
   DevPair pairs[kMaxPairs];
   DevObs obs[96];

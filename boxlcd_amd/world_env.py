@@ -250,6 +250,7 @@ class WorldEnv(_EnvSpec):
     h = self._handle()
     self.ep_t = 0
     poses, sel = self._sample_poses(lambda lo, hi: np.array([self.np_random.uniform(lo, hi)]), 1)
+    self._sel = sel
     h.reset(None, poses, sel)
     if proprio is not None:
       pshape = self.observation_space.spaces['proprio'].shape
@@ -277,18 +278,36 @@ class WorldEnv(_EnvSpec):
     return self._get_obs(), reward, done, info
 
   def lcd_render(self, width=None, height=None, lcd_mode='1'):
+    """reference world_env.py:460-512: any canvas size, lcd_mode '1' (bool [H, W]) or 'RGB' (uint8 [H, W, 3])."""
     lcd_mode = lcd_mode.upper()
     assert lcd_mode in ['1', 'RGB'], 'lcd_mode must be in one of these PIL supported modes'
     dw, dh = int(self.G.lcd_base * self.G.wh_ratio), self.G.lcd_base
-    if (width is not None or height is not None) and (width, height) != (dw, dh) or lcd_mode != '1':
-      raise NotImplementedError('only the native binary LCD is rendered on device (display-only modes are out of scope)')
-    _, lcd = self._handle().get_obs(None)
-    return lcd[0].astype(bool)
+    if width is None and height is None:
+      width, height = dw, dh
+    h = self._handle()
+    if lcd_mode == '1' and (width, height) == (dw, dh):
+      _, lcd = h.get_obs(None)
+      return lcd[0].astype(bool)
+    img = h.render_poses_ex(h.get_poses()[:, :, :3], self._sel, int(width), int(height), lcd_mode)[0]
+    return img.astype(bool) if lcd_mode == '1' else img
 
   def render(self, mode='rgb_array', lcd_mode='1', return_pyglet_view=False):
-    if mode != 'rgb_array':
-      raise NotImplementedError("mode='human' (pyglet viewer) is out of scope; use mode='rgb_array'")
-    return self.lcd_render(lcd_mode=lcd_mode)
+    """reference world_env.py:514-535.  mode='human' composes the same side-by-side frame (8x RGB view | separator | LCD x8)
+    the reference hands to its pyglet viewer; no window is opened here - pass return_pyglet_view=True to get the frame."""
+    lcd_mode = lcd_mode.upper()
+    width, height = int(self.G.lcd_base * self.G.wh_ratio), self.G.lcd_base
+    lcd = self.lcd_render(width, height, lcd_mode=lcd_mode)
+    if mode == 'rgb_array':
+      return lcd
+    if mode != 'human':
+      raise ValueError(mode)
+    high_res = self.lcd_render(width * 8, height * 8, lcd_mode='RGB').astype(np.uint8)
+    if lcd_mode == 'RGB':
+      low_res = lcd.astype(np.uint8).repeat(8, 0).repeat(8, 1)
+    else:
+      low_res = 255 * lcd.astype(np.uint8)[..., None].repeat(8, 0).repeat(8, 1).repeat(3, 2)
+    img = np.concatenate([high_res, np.zeros_like(low_res)[:, :1], low_res], axis=1)
+    return img if return_pyglet_view else lcd
 
 
 class BatchedWorldEnv(_EnvSpec):
@@ -342,6 +361,9 @@ class BatchedWorldEnv(_EnvSpec):
     n = len(idxs)
     poses, sel = self.sample_initial(n)
     h.reset(idxs, poses, sel)
+    if getattr(self, '_sel', None) is None:
+      self._sel = np.zeros((self.num_envs, len(self.scene.bodies)), np.int32)
+    self._sel[idxs] = sel
     self.ep_t[idxs] = 0
     if proprio is not None:
       fs = np.zeros((n, self.obs_size))
@@ -363,6 +385,19 @@ class BatchedWorldEnv(_EnvSpec):
     done = self.ep_t >= self.G.ep_len
     infos = [{'timeout': bool(d)} for d in done]
     return self._obs(), np.zeros(self.num_envs, np.float64), done, infos
+
+  def lcd_render(self, width=None, height=None, lcd_mode='1'):
+    """Batched reference world_env.py:460-512: bool [N, H, W] for '1', uint8 [N, H, W, 3] for 'RGB', any canvas size."""
+    lcd_mode = lcd_mode.upper()
+    assert lcd_mode in ['1', 'RGB'], 'lcd_mode must be in one of these PIL supported modes'
+    dw, dh = int(self.G.lcd_base * self.G.wh_ratio), self.G.lcd_base
+    if width is None and height is None:
+      width, height = dw, dh
+    h = self._handle()
+    if lcd_mode == '1' and (width, height) == (dw, dh):
+      return h.get_obs(None)[1].astype(bool)
+    img = h.render_poses_ex(h.get_poses()[:, :, :3], self._sel, int(width), int(height), lcd_mode)
+    return img.astype(bool) if lcd_mode == '1' else img
 
   def render_states(self, full_state):
     """state -> LCD for M normalised states (the `env.reset(proprio=s)['lcd']` use), without touching env state."""

@@ -167,6 +167,16 @@ int blcd_goal_eval(blcd_handle h, double* rew, uint8_t* done, double* delta);
  * transform), shape_sel int32 [m][n_bodies] or NULL; lcd uint8 [m][lcd_h][lcd_w].  host|device. */
 int blcd_render_poses(blcd_handle h, const float* poses, const int32_t* shape_sel, int32_t m, uint8_t* lcd);
 
+/* Replaces `WorldEnv.lcd_render(width, height, lcd_mode)` (boxLCD/world_env.py:460-512) for explicit canvas sizes and for
+ * lcd_mode='RGB' - i.e. also the 8x view `render(mode='human')` composes (world_env.py:514-535).  mode 0 = '1': out uint8
+ * [m][height][width], 1 = background (fill only); mode 1 = 'RGB': out uint8 [m][height][width][3], body.color1 fill + 1-px
+ * body.color2 outline, already `255 - image` as the reference returns it.  Both axes scale by width / WIDTH, as upstream.
+ * Circles come from Pillow's ellipse span table, which the caller hands over once per process with
+ * blcd_set_ellipse_rgb_lut (file boxlcd_amd/ellipse_rgb_lut.bin: uint8 [amax+1][5][amax+3][6], amax = 100).  host|device. */
+int blcd_set_ellipse_rgb_lut(const uint8_t* lut /* host */, int32_t amax);
+int blcd_render_poses_ex(blcd_handle h, const float* poses, const int32_t* shape_sel, int32_t m, int32_t width, int32_t height,
+                         int32_t mode, uint8_t* out);
+
 /* Body poses for host-side consumers: float32 [n_envs][n_bodies][4] = transform.position.x, .y, body.angle, awake. */
 int blcd_get_poses(blcd_handle h, float* poses);
 

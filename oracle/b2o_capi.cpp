@@ -164,6 +164,87 @@ static void RenderBodies(const b2o_scene_desc& S, int n, const Shape* shapes, co
   for (int r = 0; r < H; ++r) std::memcpy(lcd + (size_t)r * W, img.data() + (size_t)(H - 1 - r) * W, W);
 }
 
+// lcd_render(width, height, lcd_mode) — reference world_env.py:460-512 with explicit size and mode: mode 0 = '1' (uint8 [H][W],
+// 1 = background, fill only), mode 1 = 'RGB' (uint8 [H][W][3] AFTER the reference's `255 - lcd`: fill by body.color1, 1-px
+// outline by body.color2; colours world_env.py:201,303,482-483).  Both axes scale by width / WIDTH (world_env.py:495-503).
+static bool RenderBodiesEx(const b2o_scene_desc& S, int n, const Shape* shapes, const Transform* xfs, int W, int H, int mode, uint8_t* out) {
+  const int C = mode ? 3 : 1;
+  std::vector<uint8_t> img((size_t)W * H * C, 1);
+  Canvas cv{W, H, img.data()};
+  cv.C = C;
+  double WIDTH = (double)S.world_w, width = (double)W;
+  bool ok = true;
+  for (int i = 0; i < n; ++i) {
+    const Shape& sh = shapes[i];
+    const Transform& xf = xfs[i];
+    const bool robot = S.bodies[i].kind != 0;
+    // int(255.0 * (1 - x)) of color1 / color2
+    const uint8_t fillc[3] = {(uint8_t)(robot ? 25 : 127), 153, (uint8_t)(robot ? 153 : 25)};
+    const uint8_t outc[3] = {(uint8_t)(robot ? 127 : 178), 178, 127};
+    const uint8_t zero[3] = {0, 0, 0};
+    if (sh.type == kCircle) {
+      double px = (double)xf.p.x, py = (double)xf.p.y, rad = (double)sh.radius;
+      double tlx = (px - rad) / WIDTH * width, tly = (py - rad) / WIDTH * width;
+      double brx = (px + rad) / WIDTH * width, bry = (py + rad) / WIDTH * width;
+      ok = draw_ellipse_rgb(cv, (int)tlx, (int)tly, (int)brx, (int)bry, mode ? fillc : zero, mode ? outc : nullptr) && ok;
+    } else {
+      int xy[2 * kMaxPolygonVertices];
+      for (int k = 0; k < sh.count; ++k) {
+        Vec2 p = Mul(xf, sh.v[k]);
+        xy[2 * k] = (int)((double)p.x / WIDTH * width);
+        xy[2 * k + 1] = (int)((double)p.y / WIDTH * width);
+      }
+      std::memcpy(cv.ink, mode ? fillc : zero, 3);
+      draw_polygon(cv, xy, sh.count, S.raster_variant);
+      if (mode) {
+        std::memcpy(cv.ink, outc, 3);
+        draw_polygon_outline(cv, xy, sh.count);
+      }
+    }
+  }
+  for (int r = 0; r < H; ++r)
+    for (int x = 0; x < W * C; ++x) {
+      uint8_t v = img[(size_t)(H - 1 - r) * W * C + x];
+      out[(size_t)r * W * C + x] = mode ? (uint8_t)(255 - v) : v;
+    }
+  return ok;
+}
+
+void b2o_set_ellipse_rgb_lut(const uint8_t* lut, int32_t amax) {
+  g_ellipse_rgb_lut = lut;
+  g_ellipse_rgb_amax = amax;
+}
+
+int32_t b2o_render_ex(b2o_env* e, int32_t width, int32_t height, int32_t mode, uint8_t* out) {
+  const b2o_scene_desc& S = e->scene;
+  Shape shapes[B2O_MAX_BODIES];
+  Transform xfs[B2O_MAX_BODIES];
+  for (int i = 0; i < S.n_bodies; ++i) {
+    shapes[i] = e->world.bodies[4 + i].shape;
+    xfs[i] = e->world.bodies[4 + i].xf;
+  }
+  return RenderBodiesEx(S, S.n_bodies, shapes, xfs, width, height, mode, out) ? 0 : -1;
+}
+
+int32_t b2o_render_poses_ex(const b2o_scene_desc* scene, const float* poses, const int32_t* shape_sel, int32_t n, int32_t width,
+                            int32_t height, int32_t mode, uint8_t* out) {
+  const b2o_scene_desc& S = *scene;
+  bool ok = true;
+  for (int k = 0; k < n; ++k) {
+    Shape shapes[B2O_MAX_BODIES];
+    Transform xfs[B2O_MAX_BODIES];
+    for (int i = 0; i < S.n_bodies; ++i) {
+      int sel = shape_sel ? shape_sel[k * S.n_bodies + i] : 0;
+      shapes[i] = BuildShape(S.shapes[S.bodies[i].shape[sel]]);
+      const float* p = poses + ((size_t)k * S.n_bodies + i) * 3;
+      xfs[i].p = V2(p[0], p[1]);
+      xfs[i].q.Set(p[2]);
+    }
+    ok = RenderBodiesEx(S, S.n_bodies, shapes, xfs, width, height, mode, out + (size_t)k * width * height * (mode ? 3 : 1)) && ok;
+  }
+  return ok ? 0 : -1;
+}
+
 void b2o_render(b2o_env* e, uint8_t* lcd) {
   const b2o_scene_desc& S = e->scene;
   Shape shapes[B2O_MAX_BODIES];

@@ -18,7 +18,9 @@ namespace b2o {
 
 struct Canvas {
   int W, H;
-  uint8_t* px;  // H*W, 1 = background, 0 = body; image coordinates (y down), not yet flipped
+  uint8_t* px;  // H*W*C; mode '1': C = 1, 1 = background, 0 = body; image coordinates (y down), not yet flipped
+  int C = 1;
+  uint8_t ink[3] = {0, 0, 0};   // current drawing colour
 };
 
 static inline void hline(Canvas& im, int x0, int y0, int x1) {
@@ -27,8 +29,75 @@ static inline void hline(Canvas& im, int x0, int y0, int x1) {
     else if (x0 >= im.W) return;
     if (x1 < 0) return;
     else if (x1 >= im.W) x1 = im.W - 1;
-    if (x0 <= x1) std::memset(im.px + y0 * im.W + x0, 0, x1 - x0 + 1);
+    for (int x = x0; x <= x1; ++x)
+      for (int c = 0; c < im.C; ++c) im.px[((size_t)y0 * im.W + x) * im.C + c] = im.ink[c];
   }
+}
+static inline void point(Canvas& im, int x, int y) {
+  if (x >= 0 && x < im.W && y >= 0 && y < im.H)
+    for (int c = 0; c < im.C; ++c) im.px[((size_t)y * im.W + x) * im.C + c] = im.ink[c];
+}
+
+// ImagingDrawLine (Draw.c line8/line32): Bresenham from (x0,y0) to (x1,y1), both end points drawn; the error term starts from
+// the FIRST point, so the pixel pattern depends on the direction (probed against Pillow 12.2, tests/test_oracle_raster.py)
+static inline void draw_line(Canvas& im, int x0, int y0, int x1, int y1) {
+  int dx = x1 - x0, dy = y1 - y0, xs = 1, ys = 1;
+  if (dx < 0) dx = -dx, xs = -1;
+  if (dy < 0) dy = -dy, ys = -1;
+  if (dx == 0) {
+    for (int i = 0; i <= dy; ++i, y0 += ys) point(im, x0, y0);
+  } else if (dy == 0) {
+    for (int i = 0; i <= dx; ++i, x0 += xs) point(im, x0, y0);
+  } else if (dx > dy) {
+    int n = dx;
+    dy += dy;
+    int e = dy - dx;
+    dx += dx;
+    for (int i = 0; i <= n; ++i) {
+      point(im, x0, y0);
+      if (e >= 0) { y0 += ys; e -= dx; }
+      e += dy;
+      x0 += xs;
+    }
+  } else {
+    int n = dy;
+    dx += dx;
+    int e = dx - dy;
+    dy += dy;
+    for (int i = 0; i <= n; ++i) {
+      point(im, x0, y0);
+      if (e >= 0) { x0 += xs; e -= dy; }
+      e += dx;
+      y0 += ys;
+    }
+  }
+}
+// ImagingDrawPolygon(fill=0, width=1): the edges in order, then the closing edge
+static inline void draw_polygon_outline(Canvas& im, const int* xy, int count) {
+  for (int i = 0; i < count - 1; ++i) draw_line(im, xy[2 * i], xy[2 * i + 1], xy[2 * i + 2], xy[2 * i + 3]);
+  draw_line(im, xy[2 * (count - 1)], xy[2 * (count - 1) + 1], xy[0], xy[1]);
+}
+
+// Ellipse with fill + 1-px outline on a near-round bbox: Pillow's span table (tools/gen_ellipse_rgb_lut.py), handed over by
+// the loader (pyb2o.load -> b2o_set_ellipse_rgb_lut).  uint8 [amax+1][5][amax+3][6]
+static const uint8_t* g_ellipse_rgb_lut = nullptr;
+static int g_ellipse_rgb_amax = -1;
+static inline bool draw_ellipse_rgb(Canvas& im, int x0, int y0, int x1, int y1, const uint8_t* fill, const uint8_t* outline) {
+  int a = x1 - x0, b = y1 - y0;
+  if (a < 0 || b < 0 || a > g_ellipse_rgb_amax || b - a < -2 || b - a > 2 || !g_ellipse_rgb_lut) return false;
+  const uint8_t* t = g_ellipse_rgb_lut + ((size_t)(a * 5 + (b - a + 2)) * (g_ellipse_rgb_amax + 3)) * 6;
+  if (fill) {
+    std::memcpy(im.ink, fill, 3);
+    for (int r = 0; r <= b; ++r)
+      if (t[6 * r] != 255) hline(im, x0 + t[6 * r], y0 + r, x0 + t[6 * r + 1]);
+  }
+  if (outline) {
+    std::memcpy(im.ink, outline, 3);
+    for (int r = 0; r <= b; ++r)
+      for (int q = 2; q < 6; q += 2)
+        if (t[6 * r + q] != 255) hline(im, x0 + t[6 * r + q], y0 + r, x0 + t[6 * r + q + 1]);
+  }
+  return true;
 }
 
 static inline int RoundUp(float f) { return (int)(f >= 0.0f ? floor(f + 0.5f) : -floor(fabs(f) + 0.5f)); }

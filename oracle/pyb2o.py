@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_build', 'libb2oracle.so')
 BODY_F, JOINT_F, PAIR_F = 12, 5, 18
 _lib = None
+_ellipse_rgb_lut = None
 
 
 def build():
@@ -27,6 +28,13 @@ def load():
     _lib.b2o_rollout.restype = C.c_double
     _lib.b2o_num_pairs.restype = C.c_int32
     _lib.b2o_contact_order.restype = C.c_int32
+    global _ellipse_rgb_lut
+    _ellipse_rgb_lut = np.fromfile(os.path.join(_HERE, 'ellipse_rgb_lut.bin'), np.uint8)   # Pillow span table (DATA)
+    amax = 0
+    while (amax + 1) * 5 * (amax + 3) * 6 < _ellipse_rgb_lut.size:
+      amax += 1
+    assert (amax + 1) * 5 * (amax + 3) * 6 == _ellipse_rgb_lut.size
+    _lib.b2o_set_ellipse_rgb_lut(_p(_ellipse_rgb_lut), amax)
   return _lib
 
 
@@ -81,6 +89,15 @@ class OracleEnv:
   def render(self):
     img = np.zeros((self.h, self.w), np.uint8)
     self.lib.b2o_render(self._e, _p(img))
+    return img
+
+  def render_ex(self, width, height, mode='1'):
+    """lcd_render(width, height, lcd_mode): mode '1' -> uint8 [H, W]; 'RGB' -> uint8 [H, W, 3]"""
+    rgb = mode.upper() == 'RGB'
+    img = np.zeros((height, width, 3) if rgb else (height, width), np.uint8)
+    rc = self.lib.b2o_render_ex(self._e, int(width), int(height), int(rgb), _p(img))
+    if rc != 0:
+      raise ValueError('ellipse bbox outside the span table')
     return img
 
   def pair_table(self):
@@ -149,6 +166,18 @@ def render_poses(desc, poses, shape_sel=None):
   sel = None if shape_sel is None else np.ascontiguousarray(shape_sel, np.int32)
   img = np.zeros((n, desc.lcd_h, desc.lcd_w), np.uint8)
   lib.b2o_render_poses(C.byref(desc), _p(poses), _p(sel), n, _p(img))
+  return img
+
+
+def render_poses_ex(desc, poses, shape_sel, width, height, mode='1'):
+  lib = load()
+  poses = np.ascontiguousarray(poses, np.float32)
+  n = poses.shape[0]
+  sel = None if shape_sel is None else np.ascontiguousarray(shape_sel, np.int32)
+  rgb = mode.upper() == 'RGB'
+  img = np.zeros((n, height, width, 3) if rgb else (n, height, width), np.uint8)
+  if lib.b2o_render_poses_ex(C.byref(desc), _p(poses), _p(sel), n, int(width), int(height), int(rgb), _p(img)) != 0:
+    raise ValueError('ellipse bbox outside the span table')
   return img
 
 

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import boxlcd_amd as B
+from boxlcd_amd._lib import Handle
 
 pytestmark = pytest.mark.gpu
 
@@ -81,3 +82,41 @@ def test_barrel_writer_matches_reference_layout(tmp_path):
   import torch
   elems = {k: torch.as_tensor(b[k], dtype=torch.float32) for k in b.keys()}     # research/data.py:149
   assert elems['lcd'].max() <= 1.0 and elems['lcd'].min() >= 0.0
+
+
+@pytest.mark.parametrize('name', ['Dropbox', 'Bounce2', 'Object2', 'Urchin', 'LuxoBall', 'UrchinCubes', 'Crab'])
+def test_render_poses_ex_equals_pillow_and_oracle(name):
+  """blcd_render_poses_ex = lcd_render(width, height, lcd_mode) (reference world_env.py:460-512) on the device: the 8x RGB
+  human view, native-size RGB, an odd non-proportional RGB canvas and a larger mode-'1' canvas, against Pillow goldens
+  (tools/gen_pillow_rgb_goldens.py) and the oracle's sequential renderer."""
+  from oracle import pyb2o
+  g = np.load('tests/golden/pillow_rgb.npz')
+  env = B.BatchedWorldEnv(name, 1, raster_variant=1)
+  d = env.scene.desc
+  poses, sel = g[name + '_poses'], g[name + '_sel']
+  h = Handle(d, 1, 0)
+  for si in range(4):
+    w, hh, rgb = g[f'{name}_size{si}'].tolist()
+    got = h.render_poses_ex(poses, sel, w, hh, 'RGB' if rgb else '1')
+    assert (got == g[f'{name}_frames{si}']).all(), (name, si)
+    assert (got == pyb2o.render_poses_ex(d, poses, sel, w, hh, 'RGB' if rgb else '1')).all()
+  h.close()
+
+
+def test_lcd_render_rgb_and_human_view_of_a_live_env():
+  """WorldEnv.lcd_render(w, h, 'RGB') / render(mode='human', return_pyglet_view=True): the 8x RGB half of the UrchinBall
+  recording, frame by frame, from the HIP path (same replay as tests/test_oracle_replay.py)."""
+  import replay as R
+  env = B.envs.UrchinBall(raster_variant=2)
+  rgb, lcd = R.fixtures('UrchinBall')
+  env.seed(7)
+  env.reset()
+  rs = np.random.RandomState(4)
+  for t in range(40):
+    env.step(rs.uniform(-1, 1, env.act_size))
+    view = env.render(mode='human', return_pyglet_view=True)
+    W8 = rgb.shape[2]
+    assert (view[:, :W8] == rgb[t]).all(), t
+    assert ((view[::8, W8 + 1::8, 0] > 127) == (lcd[t] > 0)).all(), t
+  assert env.lcd_render(50, 30, '1').shape == (30, 50) and env.lcd_render(50, 30, 'RGB').shape == (30, 50, 3)
+  env.close()
