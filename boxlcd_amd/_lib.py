@@ -71,10 +71,15 @@ def load():
   return lib
 
 
+class EnvFaultError(RuntimeError):
+  """BLCD_ERR_ENV_FAULT: the call completed, but at least one environment carries a device fault flag (Handle.faults())."""
+
+
 def _check(rc):
   if rc != 0:
     msg = load().blcd_last_error()
-    raise RuntimeError(f'boxlcd_hip error {rc}: {msg.decode() if msg else "?"}')
+    text = f'boxlcd_hip error {rc}: {msg.decode() if msg else "?"}'
+    raise (EnvFaultError if rc == -5 else RuntimeError)(text)
 
 
 def _ptr(x):

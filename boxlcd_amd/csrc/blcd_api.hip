@@ -565,6 +565,7 @@ struct blcd_handle_s {
   int lastLaunches = 0;
   // staging
   void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* dFaultAny = nullptr;  // device flag raised by step_kernel when an environment is faulted
   uint8_t* dLut = nullptr;   // Pillow's ellipse span table for blcd_render_poses_ex (uploaded on first use)
   int lutAmax = -1;
   int* dErr = nullptr;
@@ -665,7 +666,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
     e1 = h->ev1;
   }
   HIPCHK(hipEventRecord(e0, h->stream));
-  StepArgs A{h->dScene, h->st, h->N, h->eid, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut};
+  StepArgs A{h->dScene, h->st, h->N, h->eid, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, h->stream, A); \
@@ -848,6 +849,8 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipMalloc((void**)&h->dFaultAny, sizeof(int)));
+  HIPCHK(hipMemset(h->dFaultAny, 0, sizeof(int)));
   HIPCHK(hipEventCreate(&h->ev1));
   HIPCHK(hipMalloc((void**)&h->dScene, sizeof(DevScene)));
   HIPCHK(hipMemcpy(h->dScene, &h->hostScene, sizeof(DevScene), hipMemcpyHostToDevice));
@@ -888,6 +891,7 @@ int blcd_destroy(blcd_handle h) {
     if (h->stage[k]) (void)hipFree(h->stage[k]);
   for (void* q : {(void*)h->dGoal, (void*)h->goalFs, (void*)h->goalLast, (void*)h->goalObs, (void*)h->goalLcd, (void*)h->goalCurLcd})
     if (q) (void)hipFree(q);
+  if (h->dFaultAny) (void)hipFree(h->dFaultAny);
   if (h->dLut) (void)hipFree(h->dLut);
   if (h->dErr) (void)hipFree(h->dErr);
   if (h->st) (void)hipFree(h->st);
@@ -950,6 +954,16 @@ int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* p
   return BLCD_OK;
 }
 
+// after the stream has drained: did any environment end the launch sequence with a fault flag?  (the flag is re-armed)
+static int fault_status(blcd_handle h) {
+  int any = 0;
+  HIPCHK(hipMemcpy(&any, h->dFaultAny, sizeof(int), hipMemcpyDeviceToHost));
+  if (!any) return BLCD_OK;
+  HIPCHK(hipMemset(h->dFaultAny, 0, sizeof(int)));
+  return fail(BLCD_ERR_ENV_FAULT, "an environment tripped a device guard (NaN state / ellipse outside the span table / island overflow): "
+                                  "the step completed; read blcd_get_faults and reset the flagged environments");
+}
+
 int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
   if (!h || n_steps < 0) return fail(BLCD_ERR_INVALID, "blcd_step: bad arguments");
   if (n_steps == 0) return BLCD_OK;
@@ -962,7 +976,7 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
   if ((rc = maybe_rebin(h, n_steps))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipEventElapsedTime(&h->lastMs, h->ev0, h->ev1));
-  return BLCD_OK;
+  return fault_status(h);
 }
 
 int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out) {
@@ -1018,7 +1032,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
   h->lastMs = total;
   if ((rc = out_done(h, 1, lcd_out, lcdStep * T, dLcd))) return rc;
   if ((rc = out_done(h, 2, obs_out, obsStep * T * sizeof(float), dObs))) return rc;
-  return BLCD_OK;
+  return fault_status(h);
 }
 
 int blcd_get_obs(blcd_handle h, void* full_state, int32_t dtype, uint8_t* lcd) {

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       const int* __restrict__ eid, const float* __restrict__ actions,
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
-                                                      uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut) {
+                                                      uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny) {
   __shared__ uint32_t ldsRows[64 * 17];   // LCD row masks of the wave's 64 environments (stride 17: conflict-free)
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
   }
   env.checkFault();
+  if (env.fault && faultAny) *faultAny = 1;
   env.store(st, N, slot);
   if (waveTimes) {
     // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
 }
 
 // b2Body::SetTransform per masked body: position first, then angle (two calls, like `body.position=`; `body.angle=`),
-// each followed by proxy synchronisation with zero displacement; new contacts are looked for at the next step.
+// each followed by proxy synchronisation with zero displacement and - Box2D 2.3.0 - m_contactManager.FindNewContacts(), which
+// also consumes the moves buffered when the bodies were created (reset), so contacts appear in the reference's order.
 template <int NB, int NJ, int NP, int SH>
 __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, const int* __restrict__ slotOf,
                                  const int* __restrict__ idxs, int n, const float* __restrict__ poses,
@@ -109,6 +111,7 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
   e = slotOf[e];
   Env<NB, NJ, NP, SH> env;
   env.load(S, st, N, e);
+  bool createdMoves = (env.wflags & WF_NEWFIXTURE) != 0;   // proxies created by reset are still in the move buffer
   for (int i = 0; i < S->nb; ++i) {
     if (mask && !mask[i]) continue;
     const float* p = poses + ((size_t)k * S->nb + i) * 3;
@@ -123,10 +126,10 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
       env.c0[i] = env.c[i];
       env.a0[i] = angle;
       env.synchronizeProxy(i, xf, xf);
+      env.findNewContacts(createdMoves);
+      createdMoves = false;
     }
   }
-  // the reference's setters call FindNewContacts immediately; contacts are (A,B)-sorted here at the next step instead
-  env.wflags |= WF_NEWFIXTURE;
   env.store(st, N, e);
 }
 
@@ -135,7 +138,7 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.eid, A.actions,
-                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut);
+                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {
   hipLaunchKernelGGL((set_poses_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(64), 0, stream, A.S, A.st, A.N, A.slotOf, A.idxs, A.n,

@@ -24,6 +24,7 @@ struct StepArgs {
   long long actStride;
   uint8_t* lcdOut;
   float* obsOut;
+  int* faultAny;   // set to 1 by any lane whose environment carries a fault flag after the launch
 };
 struct SetPosesArgs {
   const DevScene* S;

@@ -119,7 +119,8 @@ int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* p
 
 /* Replaces WorldEnv.step(action) (world_env.py:431-458) for all envs, n_steps times with the same actions:
  * action -> motorSpeed (utils.py:117 + world_env.py:441), then `substeps` x b2World.Step(dt, vel_iters, pos_iters).
- * actions host|device float32 [n_envs][n_act] (NULL = zeros). */
+ * actions host|device float32 [n_envs][n_act] (NULL = zeros).
+ * Returns BLCD_ERR_ENV_FAULT (after completing the step) when any environment carries a fault flag: see blcd_get_faults. */
 int blcd_step(blcd_handle h, const float* actions, int32_t n_steps);
 
 /* Fused rollout, replaces the inner loop of research/data.py:56-61 (`for j in range(ep_len): venv.step(act)`):

@@ -84,6 +84,52 @@ def test_barrel_writer_matches_reference_layout(tmp_path):
   assert elems['lcd'].max() <= 1.0 and elems['lcd'].min() >= 0.0
 
 
+def test_barrel_contents_equal_the_oracle_rollout(tmp_path):
+  """A default-size barrel (1000 episodes, research/data.py:19 BARREL_SIZE) of LuxoBall: every array of the file against the
+  CPU oracle stepping the same start poses with the same action tape - lcd bit-exact, full_state/proprio to float32 rounding."""
+  from oracle import pyb2o
+  from boxlcd_amd.data import fill_barrels, BARREL_SIZE
+  assert BARREL_SIZE == 1000
+  G = {'ep_len': 9}
+  paths = fill_barrels('LuxoBall', 1, tmp_path, 'train', G, seed=11, stamp='20260101T000000')
+  b = np.load(paths[0])
+  assert b['lcd'].shape == (1000, 9, 16, 24) and b['action'].shape == (1000, 9, 3)
+  venv = B.BatchedWorldEnv('LuxoBall', BARREL_SIZE, G, seed=11)      # same Philox streams as the writer
+  poses, sel = venv.sample_initial(BARREL_SIZE)
+  d = venv.scene.desc
+  for e in range(0, BARREL_SIZE, 37):
+    o = pyb2o.OracleEnv(d)
+    o.reset(poses[e], sel[e])
+    for j in range(9):
+      assert (b['lcd'][e, j] == o.render().astype(bool)).all(), (e, j)
+      fs = o.obs()
+      assert np.abs(b['full_state'][e, j] - fs).max() < 1e-6 and np.abs(b['proprio'][e, j] - fs[venv.pobs_idxs]).max() < 1e-6
+      o.step(b['action'][e, j].astype(np.float32))
+  venv.close()
+
+
+def test_env_fault_is_returned_by_step():
+  """BLCD_ERR_ENV_FAULT: a poisoned environment (NaN pose) makes blcd_step / blcd_rollout report it, the others keep running."""
+  from boxlcd_amd._lib import EnvFaultError
+  venv = B.BatchedWorldEnv('Object2', 64, seed=2)
+  venv.reset()
+  h = venv._handle()
+  h.step(None, 2)
+  bad = h.get_poses()[5:6, :, :3].copy()
+  bad[0, 0, 0] = np.nan
+  h.set_poses(np.array([5], np.int32), bad, None)
+  with pytest.raises(EnvFaultError):
+    h.step(None, 1)
+  f = h.faults()
+  assert f[5] != 0 and (np.delete(f, 5) == 0).all()
+  with pytest.raises(EnvFaultError):
+    h.rollout(None, 3)
+  venv.reset(idxs=[5])
+  h.step(None, 1)                       # cleared by the reset
+  assert not h.faults().any()
+  venv.close()
+
+
 @pytest.mark.parametrize('name', ['Dropbox', 'Bounce2', 'Object2', 'Urchin', 'LuxoBall', 'UrchinCubes', 'Crab'])
 def test_render_poses_ex_equals_pillow_and_oracle(name):
   """blcd_render_poses_ex = lcd_render(width, height, lcd_mode) (reference world_env.py:460-512) on the device: the 8x RGB

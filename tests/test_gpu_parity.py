@@ -19,8 +19,8 @@ def test_baseline_configs_bit_exact_per_world_step(name, n, steps):
   assert cnt == steps * 3 and not msgs, msgs[:5]
 
 
-@pytest.mark.parametrize('name', ['Bounce2', 'Object3', 'Luxo', 'UrchinCube', 'LuxoCube', 'UrchinBall', 'UrchinBalls',
-                                  'LuxoCubes', 'Crab', 'CrabCube', 'SpiderCube'])
+@pytest.mark.parametrize('name', ['Bounce2', 'Object3', 'Luxo', 'UrchinCube', 'LuxoCube', 'UrchinBall', 'UrchinBalls', 'LuxoBalls',
+                                  'UrchinCubes', 'LuxoCubes', 'Crab', 'CrabCube', 'SpiderCube'])
 def test_rest_of_catalogue_bit_exact(name):
   cnt, msgs = parity.run_substep_parity(name, 32, 60, seed=5)
   assert not msgs, msgs[:5]
@@ -141,15 +141,85 @@ def test_partial_reset_and_set_poses():
   for e in idxs:
     o = pyb2o.OracleEnv(env.scene.desc); o.reset(poses[e], sel[e]); oras.append(o)
   assert all((after[e] == o.dump()[0]).all() for e, o in zip(idxs, oras))
-  # SetTransform path: poses/LCD equal the oracle's (contact order may differ by design)
+  # SetTransform path (reset(full_state=), world_env.py:333-380): FindNewContacts after every setter, as Box2D 2.3.0 does -
+  # the whole state (bodies incl. fat AABBs, pairs, contact order through the following steps) equals the oracle's
   newp = poses[idxs].copy(); newp[..., 0] = 2.5; newp[:, 0, 1] = 1.0; newp[:, 1, 1] = 3.0; newp[..., 2] = 0.3
   h.set_poses(idxs, newp, None)
   for o, p in zip(oras, newp):
     o.set_poses(p)
   _, lcd = h.get_obs(None)
-  d = h.debug_dump()[0]
+  db, _, dp = h.debug_dump()
   for e, o in zip(idxs, oras):
-    assert (lcd[e] == o.render()).all() and (d[e][:, :6] == o.dump()[0][:, :6]).all()
+    ob, _, op = o.dump()
+    assert (lcd[e] == o.render()).all() and (db[e] == ob).all() and (dp[e][:len(op)] == op).all()
+  h.close()
+
+
+@pytest.mark.parametrize('name', ['Object3', 'UrchinBalls', 'LuxoCubes'])
+def test_state_injection_right_after_reset_keeps_contact_order(name):
+  """reset(full_state=) as the reference runs it: fresh bodies (proxies still in the move buffer), then two SetTransforms per
+  body with FindNewContacts after each.  Bodies are injected on top of each other / of the floor so that several contacts
+  appear at t = 0; the order they are created in decides the solver order, so 30 env-steps later every state word must still
+  equal the oracle's."""
+  n = 48
+  env = B.BatchedWorldEnv(name, n, seed=21)
+  poses, sel = env.sample_initial(n)
+  h = Handle(env.scene.desc, n, 0)
+  h.reset(None, poses, sel)
+  inj = poses.copy()
+  nb = inj.shape[1]
+  rng = np.random.RandomState(3)
+  inj[:, :, 0] = 2.0 + 0.35 * np.arange(nb)[None, :] + rng.uniform(-0.05, 0.05, (n, nb))   # a touching row of bodies...
+  inj[:, :, 1] = 0.55 + rng.uniform(0.0, 0.1, (n, nb))                                     # ...resting on the floor
+  if env.scene.desc.n_joints:                                                                # robots: keep links on their anchors
+    inj[:, :env.scene.desc.n_joints + 1] = poses[:, :env.scene.desc.n_joints + 1]
+    inj[:, env.scene.desc.n_joints + 1:, 0] = poses[:, 0:1, 0] + 0.4 * (1 + np.arange(nb - env.scene.desc.n_joints - 1))[None, :]
+  h.set_poses(None, inj, None)
+  acts = env.sample_actions(30)
+  oras = []
+  for e in range(n):
+    o = pyb2o.OracleEnv(env.scene.desc)
+    o.reset(poses[e], sel[e])
+    o.set_poses(inj[e])
+    oras.append(o)
+  db, dj, dp = h.debug_dump()
+  for e, o in enumerate(oras):
+    ob, oj, op = o.dump()
+    assert (db[e] == ob).all() and (dp[e][:len(op)] == op).all(), e
+  created = sum(int((o.dump()[2][:, 0] > 0).sum()) for o in oras)
+  assert created >= 3 * n                                   # several contacts per environment exist before the first step
+  for t in range(30):
+    h.step(acts[t], 1)
+    for e, o in enumerate(oras):
+      o.step(acts[t, e])
+  db, dj, dp = h.debug_dump()
+  for e, o in enumerate(oras):
+    ob, oj, op = o.dump()
+    assert (db[e] == ob).all() and (dj[e][:len(oj)] == oj).all() and (dp[e][:len(op)] == op).all(), e
+  assert not h.faults().any()
+  h.close()
+
+
+@pytest.mark.parametrize('name,n,T', [('Urchin', 50_000, 40), ('LuxoBall', 50_000, 30), ('Object2', 200_000, 60)])
+def test_full_size_baseline_batches(name, n, T):
+  """BASELINE configs[2..4] at their full batch sizes (one GPU's worth; the 8-GPU configs shard exactly this): fused rollout,
+  no faults, physical bounds, every environment drawn, and a 64-environment sample of the batch against the oracle."""
+  env = B.BatchedWorldEnv(name, n, seed=31)
+  poses, sel = env.sample_initial(n)
+  acts = env.sample_actions(T)
+  d = env.scene.desc
+  h = Handle(d, n, 0)
+  h.reset(None, poses, sel)
+  lcd_last = np.zeros((1, n, d.lcd_h, d.lcd_w), np.uint8)
+  h.rollout(acts[:T - 1], T - 1)
+  h.rollout(acts[T - 1:], 1, lcd_out=lcd_last)
+  st = h.debug_dump()[0]
+  assert np.isfinite(st).all() and not h.faults().any()
+  assert (st[:, :, 0] > -0.5).all() and (st[:, :, 0] < d.world_w + 0.5).all() and (st[:, :, 1] > -0.5).all() and (st[:, :, 1] < d.world_h + 0.5).all()
+  assert (lcd_last[0].reshape(n, -1).min(1) == 0).all()
+  idx = np.random.RandomState(1).choice(n, 64, replace=False)
+  _, _, olcd, ost = pyb2o.rollout(d, poses[idx], sel[idx], acts[:, idx], T, threads=8)
+  assert (ost == st[idx]).all() and (olcd == lcd_last[0][idx]).all()
   h.close()
 
 
