@@ -40,9 +40,6 @@ class _GoalBase:
   def render(self, *args, **kwargs):
     return self._env.render(*args, **kwargs)
 
-  def close(self):
-    self._env.close()
-
   def __getattr__(self, name):        # obs_keys, pobs_keys, num_envs, ... of the wrapped env
     return getattr(self._env, name)
 
@@ -54,9 +51,55 @@ class _GoalBase:
     """float64 full_state + LCD of the current (goal) state, as the per-process reference wrapper sees them"""
     self._goal64 = self._handle().get_obs(np.float64)
 
-  def _install(self, mode, cols, thresh, diff_delt):
+  def _install(self, mode, cols, thresh, diff_delt, idxs=None):
     fs64, lcd = self._goal64
-    self._handle().goal_set(mode, cols, thresh, _get(self.G, 'rew_scale', 1.0), diff_delt, fs64, lcd)
+    if idxs is not None:
+      fs64, lcd = fs64[idxs], lcd[idxs]
+    self._handle().goal_set(mode, cols, thresh, _get(self.G, 'rew_scale', 1.0), diff_delt, fs64, lcd, env_idxs=idxs)
+
+  # Batched envs: the reference gives every sub-environment its own wrapper, and AsyncVectorEnv.reset(idxs) only touches the
+  # listed workers (research/wrappers/async_vector_env.py:131-189).  So a goal is sampled - and, for the cube variant, settled for
+  # `settle` zero-action env-steps - in a scratch handle holding just those environments; the running ones keep their state,
+  # goal and last delta.
+  def _goal_from_scratch(self, idxs, settle):
+    env = self._env
+    n = len(idxs)
+    poses, sel = env.sample_initial(n)
+    from ._lib import Handle
+    key = n
+    if getattr(self, '_scratch', None) is None or self._scratch[0] != key:
+      if getattr(self, '_scratch', None) is not None:
+        self._scratch[1].close()
+      self._scratch = (key, Handle(env.scene.desc, n, env._device))
+    sh = self._scratch[1]
+    sh.reset(None, poses, sel)
+    if settle:
+      sh.step(None, settle)
+    fs64, lcd = sh.get_obs(np.float64)
+    if getattr(self, '_goal64', None) is None or self._goal64[0].shape[0] != env.num_envs:
+      self._goal64 = (np.zeros((env.num_envs, env.obs_size), np.float64), np.zeros((env.num_envs,) + lcd.shape[1:], np.uint8))
+      self.goal = {'full_state': np.zeros((env.num_envs, env.obs_size), np.float32), 'lcd': np.zeros((env.num_envs,) + lcd.shape[1:], bool),
+                   'proprio': np.zeros((env.num_envs, max(env.pobs_size, 1)), np.float32)}
+    self._goal64[0][idxs], self._goal64[1][idxs] = fs64, lcd
+    self.goal['full_state'][idxs] = fs64.astype(np.float32)
+    self.goal['lcd'][idxs] = lcd.astype(bool)
+    if env.pobs_size:
+      self.goal['proprio'][idxs] = fs64[:, env.pobs_idxs].astype(np.float32)
+
+  def _batched_reset(self, idxs, settle, mode, cols, thresh, kwargs):
+    env = self._env
+    idxs = np.arange(env.num_envs, dtype=np.int32) if idxs is None else np.asarray(idxs, dtype=np.int32)
+    self._goal_from_scratch(idxs, settle)
+    obs = env.reset(idxs, **kwargs)
+    self._install(mode, cols, thresh, _get(self.G, 'diff_delt', 0), idxs)
+    self._handle().goal_seed(idxs)
+    return obs
+
+  def close(self):
+    if getattr(self, '_scratch', None) is not None:
+      self._scratch[1].close()
+      self._scratch = None
+    self._env.close()
 
   def _eval(self):
     rew, done, delta = self._handle().goal_eval()
@@ -85,12 +128,16 @@ class BodyGoalEnv(_GoalBase):
     return 0 if _get(self.G, 'state_rew', 1) else 1
 
   def reset(self, *args, **kwargs):
-    self.goal = self._env.reset()                                      # body_goal.py:36: a fresh random state is the goal
-    self._snapshot_goal()
-    obs = self._env.reset(*args, **kwargs)
     thresh = _get(self.G, 'goal_thresh', 0.05) if self._mode() == 0 else 0.70
-    self._install(self._mode(), self._cols, thresh, _get(self.G, 'diff_delt', 0))
-    self._handle().goal_seed()
+    if self._batched:                                                  # reset(idxs=None, **kwargs): only the listed environments
+      idxs = args[0] if args else kwargs.pop('idxs', None)
+      obs = self._batched_reset(idxs, 0, self._mode(), self._cols, thresh, kwargs)
+    else:
+      self.goal = self._env.reset()                                    # body_goal.py:36: a fresh random state is the goal
+      self._snapshot_goal()
+      obs = self._env.reset(*args, **kwargs)
+      self._install(self._mode(), self._cols, thresh, _get(self.G, 'diff_delt', 0))
+      self._handle().goal_seed()
     obs['goal:lcd'] = np.array(self.goal['lcd'])
     obs['goal:proprio'] = np.array(self.goal['proprio'])
     self.last_obs = copy.deepcopy(obs)
@@ -143,14 +190,18 @@ class CubeGoalEnv(_GoalBase):
     obs['goal:object'] = np.array(self.goal['full_state'][..., self.idxs])
 
   def reset(self, *args, **kwargs):
-    self.goal = self._env.reset()
-    zeros = np.zeros((self._env.num_envs, self._env.act_size), np.float32) if self._batched else np.zeros(self._env.action_space.shape)
-    for i in range(10):                                                # cube_goal.py:36-37: let the goal scene settle
-      self.goal = self._env.step(zeros)[0]
-    self._snapshot_goal()
-    obs = self._env.reset(*args, **kwargs)
-    self._install(0, self.idxs, 0.05, _get(self.G, 'diff_delt', 0))
-    self._handle().goal_seed()
+    if self._batched:
+      idxs = args[0] if args else kwargs.pop('idxs', None)
+      obs = self._batched_reset(idxs, 10, 0, self.idxs, 0.05, kwargs)  # cube_goal.py:36-37: the goal scene settles for 10 steps
+    else:
+      self.goal = self._env.reset()
+      zeros = np.zeros(self._env.action_space.shape)
+      for i in range(10):                                              # cube_goal.py:36-37: let the goal scene settle
+        self.goal = self._env.step(zeros)[0]
+      self._snapshot_goal()
+      obs = self._env.reset(*args, **kwargs)
+      self._install(0, self.idxs, 0.05, _get(self.G, 'diff_delt', 0))
+      self._handle().goal_seed()
     self._add_goal(obs)
     self.last_obs = copy.deepcopy(obs)
     return obs

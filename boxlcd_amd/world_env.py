@@ -386,6 +386,56 @@ class BatchedWorldEnv(_EnvSpec):
     infos = [{'timeout': bool(d)} for d in done]
     return self._obs(), np.zeros(self.num_envs, np.float64), done, infos
 
+  # ---- device-resident surface: torch CUDA tensors in and out, no host copies, no per-env Python objects -----------------
+  # What the reference's GPU-side consumers loop over (research/rl/ppo.py:127-133 `o, r, d, info = env.step(a)`,
+  # rl/sac.py:200-214, data.py:50-77), with the vector env's call shapes but tensors that stay in HBM.
+  def _torch_bufs(self):
+    import torch
+    if getattr(self, '_tb', None) is None:
+      dev = torch.device('cuda', self._device)
+      d = self.scene.desc
+      self._tb = {'full_state': torch.empty((self.num_envs, self.obs_size), dtype=torch.float32, device=dev),
+                  'lcd': torch.empty((self.num_envs, d.lcd_h, d.lcd_w), dtype=torch.uint8, device=dev),
+                  'ep_t': torch.zeros(self.num_envs, dtype=torch.int64, device=dev),
+                  'rew': torch.zeros(self.num_envs, dtype=torch.float64, device=dev),
+                  'pidx': torch.as_tensor(np.asarray(self.pobs_idxs, np.int64), device=dev)}
+    return self._tb
+
+  def _obs_torch(self):
+    tb = self._torch_bufs()
+    self._handle().get_obs_into(tb['full_state'], tb['lcd'])
+    fs = tb['full_state']
+    proprio = fs[:, tb['pidx']] if self.pobs_size != 0 else fs.new_zeros((self.num_envs, 1))
+    return {'full_state': fs, 'proprio': proprio, 'lcd': tb['lcd']}
+
+  def reset_torch(self, idxs=None):
+    """reset(idxs) returning CUDA tensors: {'full_state' f32 [N, obs], 'proprio' f32 [N, pobs], 'lcd' uint8 [N, H, W] (0/1)}.
+    The returned tensors are views of per-env buffers that the next call overwrites (clone to keep)."""
+    import torch
+    tb = self._torch_bufs()
+    h = self._handle()
+    ii = np.arange(self.num_envs, dtype=np.int32) if idxs is None else np.asarray(torch.as_tensor(idxs).cpu() if hasattr(idxs, 'cpu') else idxs, dtype=np.int32)
+    poses, sel = self.sample_initial(len(ii))
+    h.reset(ii, poses, sel)
+    if getattr(self, '_sel', None) is None:
+      self._sel = np.zeros((self.num_envs, len(self.scene.bodies)), np.int32)
+    self._sel[ii] = sel
+    self.ep_t[ii] = 0
+    tb['ep_t'][torch.as_tensor(ii.astype(np.int64), device=tb['ep_t'].device)] = 0
+    return self._obs_torch()
+
+  def step_torch(self, actions):
+    """step(actions) on CUDA tensors: actions f32 [N, act] on the device -> (obs dict of tensors, rew f64 [N] zeros,
+    done bool [N], timeout bool [N]) - one kernel launch + one obs/raster launch, nothing crosses PCIe."""
+    tb = self._torch_bufs()
+    a = actions.contiguous() if actions.dtype == tb['full_state'].dtype else actions.float().contiguous()
+    assert a.is_cuda and tuple(a.shape) == (self.num_envs, self.act_size)
+    self._handle().step(a, 1)
+    tb['ep_t'] += 1
+    self.ep_t += 1
+    done = tb['ep_t'] >= int(self.G.ep_len)
+    return self._obs_torch(), tb['rew'], done, done
+
   def lcd_render(self, width=None, height=None, lcd_mode='1'):
     """Batched reference world_env.py:460-512: bool [N, H, W] for '1', uint8 [N, H, W, 3] for 'RGB', any canvas size."""
     lcd_mode = lcd_mode.upper()

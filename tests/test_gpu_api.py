@@ -166,3 +166,28 @@ def test_lcd_render_rgb_and_human_view_of_a_live_env():
     assert ((view[::8, W8 + 1::8, 0] > 127) == (lcd[t] > 0)).all(), t
   assert env.lcd_render(50, 30, '1').shape == (30, 50) and env.lcd_render(50, 30, 'RGB').shape == (30, 50, 3)
   env.close()
+
+
+def test_device_resident_vector_env():
+  """step_torch / reset_torch: CUDA tensors in and out (what research/rl/ppo.py:127-133-style loops need to run at kernel
+  speed); same numbers as the host-copy API stepping an identically seeded twin."""
+  import torch
+  n = 300
+  a = B.BatchedWorldEnv('LuxoBall', n, {'ep_len': 7}, seed=8)
+  b = B.BatchedWorldEnv('LuxoBall', n, {'ep_len': 7}, seed=8)
+  oa, ob = a.reset_torch(), b.reset()
+  assert oa['full_state'].is_cuda and oa['lcd'].dtype == torch.uint8 and oa['proprio'].shape == (n, a.pobs_size)
+  assert (oa['full_state'].cpu().numpy() == ob['full_state']).all() and (oa['lcd'].cpu().numpy().astype(bool) == ob['lcd']).all()
+  acts = torch.as_tensor(b.sample_actions(7)).cuda()
+  for t in range(7):
+    o, rew, done, timeout = a.step_torch(acts[t])
+    o2, rew2, done2, infos = b.step(acts[t].cpu().numpy())
+    assert rew.is_cuda and done.dtype == torch.bool and (done.cpu().numpy() == done2).all() and float(rew.sum()) == 0.0
+    assert (o['full_state'].cpu().numpy() == o2['full_state']).all() and (o['lcd'].cpu().numpy().astype(bool) == o2['lcd']).all()
+    assert (o['proprio'].cpu().numpy() == o2['proprio']).all()
+  assert bool(done.all())
+  idx = torch.tensor([2, 5, 9])
+  o = a.reset_torch(idx)
+  b.reset(idx.numpy())
+  assert (o['full_state'].cpu().numpy() == b._obs()['full_state']).all()
+  a.close(); b.close()

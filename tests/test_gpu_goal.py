@@ -1,64 +1,72 @@
-"""Goal wrappers: the device epilogue against the numpy restatement of the reference's rules."""
+"""Goal wrappers: the device epilogue (blcd_goal_set / _seed / _eval) against fixtures computed in the
+authoring container from the reference's rules (research/wrappers/body_goal.py:58-88, cube_goal.py:64-86) on the CPU oracle's
+observations - tools/gen_goal_fixtures.py -> tests/golden/goal_fixtures.npz.  Nothing here imports the rules themselves."""
+import ast
 import numpy as np
 import pytest
 import boxlcd_amd as B
+from boxlcd_amd._lib import Handle
 from boxlcd_amd.goal import BodyGoalEnv, CubeGoalEnv
-from oracle import goal_ref
 
 pytestmark = pytest.mark.gpu
+FIX = np.load('tests/golden/goal_fixtures.npz')
 
 
-def _per_env_obs(venv, k, fs64, lcd, goal64, goal_lcd):
-  pidx = venv.pobs_idxs
-  return {'full_state': fs64[k], 'proprio': fs64[k][pidx], 'lcd': lcd[k].astype(bool), 'goal:full_state': goal64[k],
-          'goal:proprio': goal64[k][pidx], 'goal:lcd': goal_lcd[k].astype(bool)}
-
-
-@pytest.mark.parametrize('name,state_rew,diff_delt', [('Urchin', 1, 0), ('Urchin', 1, 1), ('Luxo', 0, 0), ('Crab', 1, 1)])
-def test_body_goal_matches_reference_rule(name, state_rew, diff_delt):
-  n, T = 96, 12
-  G = {'state_rew': state_rew, 'diff_delt': diff_delt, 'goal_thresh': 0.35, 'rew_scale': 0.5}
-  venv = B.BatchedWorldEnv(name, n, seed=3)
-  env = BodyGoalEnv(venv, G)
-  obs = env.reset()
-  assert obs['goal:lcd'].shape == obs['lcd'].shape and obs['goal:proprio'].shape == obs['proprio'].shape
-  goal64, goal_lcd = env._goal64
-  h = venv._handle()
-  fs64, lcd = h.get_obs(np.float64)
-  last = [_per_env_obs(venv, k, fs64, lcd, goal64, goal_lcd) for k in range(n)]
-  n_done = 0
+@pytest.mark.parametrize('ci', range(7))
+def test_goal_epilogue_equals_reference_rules(ci):
+  k = f'case{ci}'
+  kind, name, G = FIX[k + '_meta'].tolist()
+  G = ast.literal_eval(G)
+  venv = B.BatchedWorldEnv(name, 1)
+  wrap = (BodyGoalEnv if kind == 'body' else CubeGoalEnv)(venv, G)
+  gposes, gsel, poses, sel, acts = (FIX[k + s] for s in ('_gposes', '_gsel', '_poses', '_sel', '_acts'))
+  n, T = poses.shape[0], acts.shape[0]
+  h = Handle(venv.scene.desc, n, 0)
+  h.reset(None, gposes, gsel)                                   # the goal: a fresh state (cube: settled for 10 zero-action steps)
+  if kind == 'cube':
+    h.step(None, 10)
+  gfs, glcd = h.get_obs(np.float64)
+  if kind == 'body':
+    mode = 0 if G['state_rew'] else 1
+    cols, thresh = wrap._cols, (G['goal_thresh'] if mode == 0 else 0.70)
+  else:
+    mode, cols, thresh = 0, wrap.idxs, 0.05
+  h.reset(None, poses, sel)
+  h.goal_set(mode, cols, thresh, G['rew_scale'], G['diff_delt'], gfs, glcd)
+  h.goal_seed()
   for t in range(T):
-    obs, rew, done, info = env.step(venv.sample_actions())
-    fs64, lcd = h.get_obs(np.float64)
-    for k in range(n):
-      cur = _per_env_obs(venv, k, fs64, lcd, goal64, goal_lcd)
-      r, d, inf = goal_ref.body_comp_rew_done(cur, last[k], venv.pobs_keys, state_rew, diff_delt, 0.35, 0.5)
-      assert rew[k] == r and bool(done[k]) == (d or info[k]['timeout']) and info[k]['delta'] == inf['delta'], (t, k, rew[k], r)
-      n_done += d
-      last[k] = cur
-  assert n_done > 0          # the thresholds are chosen so that the success branch is exercised
+    h.step(acts[t], 1)
+    rew, done, delta = h.goal_eval()
+    assert (rew == FIX[k + '_rew'][t]).all(), (t, np.abs(rew - FIX[k + '_rew'][t]).max())
+    assert (done.astype(bool) == FIX[k + '_done'][t]).all()
+    exp = FIX[k + '_delta'][t]
+    assert (delta[~np.isnan(exp)] == exp[~np.isnan(exp)]).all()
+  h.close()
 
 
-@pytest.mark.parametrize('name,diff_delt', [('UrchinCube', 1), ('LuxoCube', 0), ('UrchinCubes', 1)])
-def test_cube_goal_matches_reference_rule(name, diff_delt):
-  n, T = 64, 10
-  G = {'diff_delt': diff_delt, 'rew_scale': 2.0}
-  venv = B.BatchedWorldEnv(name, n, seed=5)
-  env = CubeGoalEnv(venv, G)
-  obs = env.reset()
-  assert obs['goal:object'].shape == (n, len(env.idxs)) and len(env.idxs) >= 2
-  goal64, goal_lcd = env._goal64
-  h = venv._handle()
-  fs64, lcd = h.get_obs(np.float64)
-  last = [_per_env_obs(venv, k, fs64, lcd, goal64, goal_lcd) for k in range(n)]
-  for t in range(T):
-    obs, rew, done, info = env.step(venv.sample_actions())
-    fs64, lcd = h.get_obs(np.float64)
-    for k in range(n):
-      cur = _per_env_obs(venv, k, fs64, lcd, goal64, goal_lcd)
-      r, d, inf = goal_ref.cube_comp_rew_done(cur, last[k], env.idxs, diff_delt, 2.0)
-      assert rew[k] == r and bool(done[k]) == (d or info[k]['timeout']), (t, k, rew[k], r)
-      last[k] = cur
+def test_wrapper_api_and_partial_reset_keeps_running_envs():
+  """reset(idxs) of a batched goal env touches only the listed environments (reference: one wrapper per worker,
+  async_vector_env.py:131-189): the others keep state, goal and last delta - their next rewards equal an undisturbed twin's."""
+  n, G = 48, {'state_rew': 1, 'diff_delt': 1, 'goal_thresh': 0.05, 'rew_scale': 1.0}
+  for cls, name in ((BodyGoalEnv, 'Urchin'), (CubeGoalEnv, 'UrchinCube')):
+    a = cls(B.BatchedWorldEnv(name, n, seed=4), G)
+    b = cls(B.BatchedWorldEnv(name, n, seed=4), G)
+    oa, ob = a.reset(), b.reset()
+    assert set(oa) >= {'full_state', 'proprio', 'lcd', 'goal:lcd', 'goal:proprio'} and (oa['goal:lcd'] == ob['goal:lcd']).all()
+    acts = a._env.sample_actions(6)
+    for t in range(3):
+      ra, rb = a.step(acts[t]), b.step(acts[t])
+      assert (ra[1] == rb[1]).all()
+    idxs = np.array([1, 7, 30], np.int32)
+    keep = np.setdiff1d(np.arange(n), idxs)
+    goal_before = a.goal['lcd'].copy()
+    o = a.reset(idxs)
+    assert (a.goal['lcd'][keep] == goal_before[keep]).all() and (o['goal:lcd'][keep] == goal_before[keep]).all()
+    for t in range(3, 6):
+      ra, rb = a.step(acts[t]), b.step(acts[t])
+      assert (ra[1][keep] == rb[1][keep]).all() and (ra[0]['full_state'][keep] == rb[0]['full_state'][keep]).all()
+      assert all(ra[3][i]['delta'] == rb[3][i]['delta'] for i in keep)
+    a.close(); b.close()
 
 
 def test_single_env_goal_wrapper():
@@ -68,7 +76,9 @@ def test_single_env_goal_wrapper():
   assert set(obs) >= {'full_state', 'proprio', 'lcd', 'goal:lcd', 'goal:proprio'}
   o2, rew, done, info = env.step(env.action_space.sample())
   assert isinstance(rew, float) and isinstance(done, bool) and 'delta' in info
-  last = {'proprio': obs['proprio'], 'goal:proprio': obs['goal:proprio']}
-  r, d, inf = goal_ref.body_comp_rew_done(o2, last, env.pobs_keys, 1, 1, 0.05, 1.0)
-  assert rew == r and info['delta'] == inf['delta']
+  # body_goal.py:58-75 by hand: mean |goal - proprio| over the x/y entries, reward -0.05 + 10 (last - now)
+  cols = [env.pobs_keys.index(k) for k in env.pobs_keys if k.endswith(('x:p', 'y:p'))]
+  now = np.abs(o2['goal:proprio'] - o2['proprio'])[cols].mean()
+  last = np.abs(obs['goal:proprio'] - obs['proprio'])[cols].mean()
+  assert info['delta'] == now and rew == (-0.05 + 10 * (last - now)) * 1.0
   env.close()

@@ -1,4 +1,4 @@
-"""ORACLE - TEST INFRASTRUCTURE ONLY.  Nothing under boxlcd_amd/ may import this.
+"""FIXTURE GENERATOR HELPER (authoring container only; used by tools/gen_goal_fixtures.py).  Nothing under boxlcd_amd/ or tests/ imports this.
 
 numpy restatement of the goal wrappers' reward rules, one environment at a time, float64 like the reference:
   body_comp_rew_done  <- research/wrappers/body_goal.py:58-88 (+ rew_scale, :98)
