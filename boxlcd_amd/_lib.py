@@ -54,6 +54,10 @@ def load():
   if not os.path.exists(LIB_PATH):
     raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                        '(hipcc --offload-arch=gfx950). boxlcd_amd has no CPU fallback.')
+  try:
+    import torch  # noqa: F401  torch bundles its own HIP runtime; it has to be the first one the process loads, or
+  except ImportError:   # `import torch` AFTER this library reports "No HIP GPUs are available" (two libamdhip64 with one soname)
+    pass
   lib = C.CDLL(LIB_PATH)
   for name, (res, args) in SYMBOLS.items():
     fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -827,6 +827,26 @@ int blcd_device_count(void) {
   return n;
 }
 
+// All handles of a device share ONE stream (created on first use, kept for the life of the process).  Every HIP stream maps
+// onto one of the runtime's hardware queues and each queue reserves scratch for the largest kernel it has run; with handles
+// spread over several queues the 17-body class (12 KB of scratch per lane) was measured to drop onto a per-dispatch
+// scratch path - 0.33 s per launch instead of 8 ms (GPU_MAX_HW_QUEUES=1 made it disappear).  Calls on different handles are
+// therefore serialised on the device; each call still ends with a stream synchronisation, as before.
+static std::mutex g_streamMutex;
+static std::vector<std::pair<int, hipStream_t>> g_deviceStream;
+static int acquire_stream(int device, hipStream_t* out) {
+  std::lock_guard<std::mutex> lock(g_streamMutex);
+  for (auto& e : g_deviceStream)
+    if (e.first == device) {
+      *out = e.second;
+      return BLCD_OK;
+    }
+  HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  g_deviceStream.emplace_back(device, *out);
+  return BLCD_OK;
+}
+static void release_stream(int, hipStream_t) {}
+
 int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, blcd_handle* out) {
   if (!scene || !out || n_envs < 1) return fail(BLCD_ERR_INVALID, "blcd_create: bad arguments");
   int ndev = blcd_device_count();
@@ -847,10 +867,10 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   h->N = n_envs;
   h->words = (size_t)stateWords(h->hostScene.nb, h->hostScene.nj, h->hostScene.np);
   HIPCHK(hipSetDevice(device));
-  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  { int rcS = acquire_stream(device, &h->stream); if (rcS) return rcS; }
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipMalloc((void**)&h->dFaultAny, sizeof(int)));
-  HIPCHK(hipMemset(h->dFaultAny, 0, sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->dFaultAny, 0, sizeof(int), h->stream));
   HIPCHK(hipEventCreate(&h->ev1));
   HIPCHK(hipMalloc((void**)&h->dScene, sizeof(DevScene)));
   HIPCHK(hipMemcpy(h->dScene, &h->hostScene, sizeof(DevScene), hipMemcpyHostToDevice));
@@ -906,7 +926,8 @@ int blcd_destroy(blcd_handle h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t ev : h->evPool) (void)hipEventDestroy(ev);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->waveTimes) (void)hipFree(h->waveTimes);
+  if (h->stream) release_stream(h->device, h->stream);
   delete h;
   return BLCD_OK;
 }
@@ -957,9 +978,10 @@ int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* p
 // after the stream has drained: did any environment end the launch sequence with a fault flag?  (the flag is re-armed)
 static int fault_status(blcd_handle h) {
   int any = 0;
-  HIPCHK(hipMemcpy(&any, h->dFaultAny, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(&any, h->dFaultAny, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   if (!any) return BLCD_OK;
-  HIPCHK(hipMemset(h->dFaultAny, 0, sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->dFaultAny, 0, sizeof(int), h->stream));
   return fail(BLCD_ERR_ENV_FAULT, "an environment tripped a device guard (NaN state / ellipse outside the span table / island overflow): "
                                   "the step completed; read blcd_get_faults and reset the flagged environments");
 }

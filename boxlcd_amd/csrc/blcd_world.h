@@ -1476,7 +1476,14 @@ struct Env {
         }
       }
     }
+#ifdef BLCD_PROF_SOLVE
+    unsigned long long ps0_ = __builtin_amdgcn_s_memtime();
+#endif
     int sweeps = R.velocitySweeps(S->velIters, h);
+#ifdef BLCD_PROF_SOLVE
+    unsigned long long ps1_ = __builtin_amdgcn_s_memtime();
+    prof[4] += ps1_ - ps0_;
+#endif
     // b2ContactSolver::StoreImpulses
 #pragma unroll
     for (int k = 0; k < kRegC; ++k) {
@@ -1519,7 +1526,13 @@ struct Env {
       }
     }
     int pit = 0;
+#ifdef BLCD_PROF_SOLVE
+    unsigned long long ps2_ = __builtin_amdgcn_s_memtime();
+#endif
     bool positionSolved = R.positionIterations(S->posIters, &pit);
+#ifdef BLCD_PROF_SOLVE
+    prof[5] += __builtin_amdgcn_s_memtime() - ps2_;
+#endif
     // copy back
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -1847,6 +1860,43 @@ struct Env {
           const float d0 = -Dot(r0, nrm), d1 = -Dot(r1, nrm);     // signed distances to the wall line (either orientation)
           const float u = Dot(r0, tan_);                           // projection parameter of the start point on the segment
           knownSeparated = u > 0.01f && u < 0.99f && ((d0 > thr && d1 > thr) || (d0 < -thr && d1 < -thr));
+        } else if constexpr (!kCirc) {
+          // Exact early-out for every other shape (polygons, circles that carry joints), by a lower bound instead of the
+          // routine's own numbers.  b2TimeOfImpact can only answer e_touching (alpha < 1) at a time t1 at which either the
+          // b2Distance of the core shapes or the separation of a vertex pair along the axis built AT t1 is below
+          // target + tolerance; that axis separates the shapes at t1, so both numbers are >= the true distance at t1, which
+          // is >= the distance of the moving vertices to the wall's LINE.  A vertex v moves as c(t) + R(a(t)) (v - lc) with c, a
+          // linear in t: its signed distance is a chord plus an arc term whose second derivative is bounded by |r| da^2, so
+          // it stays above min(D(0), D(1)) - |r| da^2 / 8.  If that bound clears the threshold for every vertex (margin 5e-4
+          // + 2e-5 for the fast sin/cos of da used here) the answer is "not touching": alpha = 1, nothing else changes.
+          const Sweep sw = sweepOf(pb_);
+          const float da = sw.a - sw.a0;
+          if (da > -1.0f && da < 1.0f) {
+            const Vec2 w0 = selGet(wallV0, pa_);
+            const Vec2 nrm = selGet(wallNrm, pa_);
+            const Shape* shB = shapeOf(pb_);
+            const float totalRadius = selGet(wallRad, pa_) + shB->radius;
+            const float thr = Max(kLinearSlop, totalRadius - 3.0f * kLinearSlop) + 0.25f * kLinearSlop + 5.0e-4f + 2.0e-5f;
+            const Rot q1 = q[b];
+            const float sd = __sinf(da), cd = __cosf(da);
+            Rot q0;                                          // R(a0) = R(a) R(-da)
+            q0.c = q1.c * cd + q1.s * sd;
+            q0.s = q1.s * cd - q1.c * sd;
+            const float lin0 = Dot(sw.c0 - w0, nrm), lin1 = Dot(sw.c - w0, nrm);
+            const float sgn = lin1 >= 0.0f ? 1.0f : -1.0f;   // the side the body ends on; a crossing fails the test below
+            const float curv = 0.125f * da * da;
+            const int nv = shB->type == kCircle ? 1 : shB->count;
+            float lowest = kMaxFloat;
+#pragma unroll
+            for (int k2 = 0; k2 < kShapeVerts; ++k2) {
+              if (k2 >= nv) break;
+              const Vec2 r = shB->v[k2] - sw.localCenter;
+              const float D0 = sgn * (lin0 + Dot(Mul(q0, r), nrm));
+              const float D1 = sgn * (lin1 + Dot(Mul(q1, r), nrm));
+              lowest = Min(lowest, Min(D0, D1) - curv * Length(r));
+            }
+            knownSeparated = lowest > thr;
+          }
         }
         if (knownSeparated) {
           output.state = kTOISeparated;
@@ -1867,7 +1917,7 @@ struct Env {
             else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
             else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
           }
-#ifndef BLCD_PROF_TOI
+#if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_SOLVE)
           prof[4] += 1;
 #endif
           if (profOn && (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) {  // once per wave-level execution
@@ -1925,7 +1975,7 @@ struct Env {
         continue;
       }
       wake(pB);
-#ifndef BLCD_PROF_TOI
+#if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_SOLVE)
       prof[5] += 1;
 #endif
       unsigned long long e0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;

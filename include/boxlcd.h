@@ -8,7 +8,9 @@
  * Conventions: every function returns 0 on success and a negative blcd_status on failure (message via
  * blcd_last_error(), thread-local).  The caller owns every buffer.  Buffers marked "host|device" may be plain
  * host memory or HIP device memory on the handle's device (detected with hipPointerGetAttributes); device buffers
- * are used in place (zero copy) on the handle's stream.  A handle is bound to one device and one HIP stream and is
+ * are used in place (zero copy) on the handle's stream.  A handle is bound to one device; all handles of a device share ONE HIP stream
+ * (a second hardware queue doubles the scratch reservation of the large scene classes, see blcd_api.hip), so calls on
+ * different handles serialise on the device.  A handle is
  * not thread-safe; different handles may be driven from different threads.  No exceptions cross the ABI.
  * There is NO CPU fallback: blcd_create fails if no HIP device is usable.
  */

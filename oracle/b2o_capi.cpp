@@ -360,6 +360,9 @@ void b2o_period_hist(b2o_env* e, int64_t* out36) {
   out36[34] = e->world.stats.cycleAtSum;
   out36[35] = e->world.stats.cycleCount;
 }
+void b2o_pos_iter_hist(b2o_env* e, int64_t* out62) {
+  for (int i = 0; i < 62; ++i) out62[i] = e->world.stats.posIterHist[i];
+}
 void b2o_stats(b2o_env* e, int64_t* out6) {
   const Stats& s = e->world.stats;
   out6[0] = s.steps; out6[1] = s.toiEvents; out6[2] = s.toiCalls; out6[3] = s.islands; out6[4] = s.contactsCreated;

@@ -133,6 +133,7 @@ struct ContactPositionConstraint {
 struct Stats {
   long steps = 0, toiEvents = 0, toiCalls = 0, islands = 0, contactsCreated = 0, contactsDestroyed = 0;
   long sweepHist[182] = {0};
+  long posIterHist[62] = {0};  // diagnostic: position iterations used per island solve (61 = not solved within the limit)
   long periodHist[34] = {0};   // diagnostic: period (1..32) of the sweep-state cycle when one is detected, [33] = none, [0] unused
   long cycleAtSum = 0, cycleCount = 0;  // diagnostic: first velocity sweep after which the state is a fixed point (181 = never)
   bool trackSweeps = false;
@@ -1266,7 +1267,9 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
     velocities[i].w = w;
   }
   bool positionSolved = false;
+  int posItersUsed = 0;
   for (int i = 0; i < step.positionIterations; ++i) {
+    ++posItersUsed;
     bool contactsOkay = contactSolver.SolvePositionConstraints();
     bool jointsOkay = true;
     for (int jid : ijoints) {
@@ -1278,6 +1281,7 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
       break;
     }
   }
+  stats.posIterHist[positionSolved ? posItersUsed : 61]++;
   for (int i = 0; i < bodyCount; ++i) {
     Body& body = bodies[ibodies[i]];
     body.sweep.c = positions[i].c;

@@ -74,11 +74,12 @@ def test_single_env_goal_wrapper():
   env.seed(2)
   obs = env.reset()
   assert set(obs) >= {'full_state', 'proprio', 'lcd', 'goal:lcd', 'goal:proprio'}
-  o2, rew, done, info = env.step(env.action_space.sample())
+  o2, rew, done, info = env.step(np.array([0.3, -0.2, 0.9], np.float32))
   assert isinstance(rew, float) and isinstance(done, bool) and 'delta' in info
   # body_goal.py:58-75 by hand: mean |goal - proprio| over the x/y entries, reward -0.05 + 10 (last - now)
   cols = [env.pobs_keys.index(k) for k in env.pobs_keys if k.endswith(('x:p', 'y:p'))]
   now = np.abs(o2['goal:proprio'] - o2['proprio'])[cols].mean()
   last = np.abs(obs['goal:proprio'] - obs['proprio'])[cols].mean()
-  assert info['delta'] == now and rew == (-0.05 + 10 * (last - now)) * 1.0
+  exp = -0.05 + 10 * (last - now) + (1.0 if now < 0.05 else 0.0)      # + success bonus below goal_thresh (body_goal.py:76-79)
+  assert info['delta'] == now and rew == exp * 1.0 and done == bool(now < 0.05 or info['timeout'])
   env.close()
