@@ -92,8 +92,12 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
     unsigned long long* o = waveTimes + (size_t)blockIdx.x * 9;
     if (threadIdx.x == 0) o[0] = __builtin_amdgcn_s_memrealtime() - t0;
+#ifdef BLCD_PROF_TOI2
+    for (int k = 0; k < 8; ++k) atomicAdd(&o[1 + k], env.prof[k]);   // wave totals (one lane records each interval)
+#else
     for (int k = 0; k < 6; ++k) atomicMax(&o[1 + k], env.prof[k]);
     for (int k = 6; k < 8; ++k) atomicAdd(&o[1 + k], env.prof[k]);
+#endif
   }
 }
 

@@ -319,6 +319,7 @@ struct RegIsland {
   }
 
   // b2PositionSolverManifold + one b2ContactSolver::SolvePositionConstraints pass over one contact; returns min separation
+  template <bool TOI = false>   // TOI: b2ContactSolver::SolveTOIPositionConstraints (b2_toiBaugarte; only the TOI body has mass)
   __device__ __forceinline__ float positionContact(const RContact& c_, float minSeparation) {
     const int pA = c_.pA, pB = c_.pB;
     BodyMass mAs = M(pA), mBs = M(pB);
@@ -363,7 +364,7 @@ struct RegIsland {
       Vec2 rA = point - cA;
       Vec2 rB = point - cB;
       minSeparation = Min(minSeparation, separation);
-      float C = Clamp(kBaumgarte * (separation + kLinearSlop), -kMaxLinearCorrection, 0.0f);
+      float C = Clamp((TOI ? kToiBaumgarte : kBaumgarte) * (separation + kLinearSlop), -kMaxLinearCorrection, 0.0f);
       float rnA = Cross(rA, normal);
       float rnB = Cross(rB, normal);
       float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;

@@ -143,24 +143,59 @@ __device__ __forceinline__ void selSet(T (&a)[N], int i, const T& v) {
   if constexpr (N <= 4) selSetImpl(a, i, v, std::make_index_sequence<N>{});
   else a[i] = v;
 }
-// up to 4 small integers packed in one register (N <= 4), plain byte array otherwise
+// Small integers (slot ids, flag bytes, counters) indexed with run-time values.  Up to 4 entries share one register; up to 32
+// are packed four to a word in (N+3)/4 registers and a run-time index becomes a compare/select over the WORDS plus a shift -
+// a byte array indexed at run time would live in scratch, and the contact-list loops (collide, island DFS, the TOI scan) read
+// these vectors several times per list position: at one wave per SIMD every such read was a ~500-cycle dependent scratch
+// load (measured: 28 M of the 40 M cycles a wave of Urchins spent in the TOI phase per 20 env-steps were this scan).
 template <int N>
 struct ByteVec {
-  uint32_t w;
-  uint8_t arr[N > 4 ? N : 1];
+  static constexpr int kWords = N <= 32 ? (N + 3) / 4 : 1;
+  uint32_t w;                        // N <= 4
+  uint32_t ww[N > 4 && N <= 32 ? kWords : 1];
+  uint8_t arr[N > 32 ? N : 1];
+  template <size_t... K>
+  __device__ __forceinline__ uint32_t wordAt(int wi, std::index_sequence<K...>) const {
+    uint32_t x = ww[0];
+    ((x = (wi == (int)(K + 1)) ? ww[K + 1] : x), ...);
+    return x;
+  }
+  template <size_t... K>
+  __device__ __forceinline__ void wordSet(int wi, uint32_t v, std::index_sequence<K...>) {
+    ((ww[K] = (wi == (int)K) ? v : ww[K]), ...);
+  }
+  __device__ __forceinline__ void clear() {
+    w = 0;
+#pragma unroll
+    for (int k = 0; k < (N > 4 && N <= 32 ? kWords : 1); ++k) ww[k] = 0;
+    if constexpr (N > 32)
+      for (int k = 0; k < N; ++k) arr[k] = 0;
+  }
   __device__ __forceinline__ int get(int i) const {
     if constexpr (N <= 4) return (int)((w >> (8 * i)) & 0xffu);
+    else if constexpr (N <= 32) return (int)((wordAt(i >> 2, std::make_index_sequence<kWords - 1>{}) >> (8 * (i & 3))) & 0xffu);
     else return arr[i];
   }
   __device__ __forceinline__ void set(int i, int v) {
-    if constexpr (N <= 4) w = (w & ~(0xffu << (8 * i))) | ((uint32_t)(v & 0xff) << (8 * i));
-    else arr[i] = (uint8_t)v;
+    if constexpr (N <= 4) {
+      w = (w & ~(0xffu << (8 * i))) | ((uint32_t)(v & 0xff) << (8 * i));
+    } else if constexpr (N <= 32) {
+      const int wi = i >> 2, sh = 8 * (i & 3);
+      const uint32_t old = wordAt(wi, std::make_index_sequence<kWords - 1>{});
+      wordSet(wi, (old & ~(0xffu << sh)) | ((uint32_t)(v & 0xff) << sh), std::make_index_sequence<kWords>{});
+    } else {
+      arr[i] = (uint8_t)v;
+    }
   }
   __device__ __forceinline__ void orBits(int i, int bits) { set(i, get(i) | bits); }
   __device__ __forceinline__ void clearBits(int i, int bits) { set(i, get(i) & ~bits); }
   __device__ __forceinline__ void insertFront(int count, int v) {  // shift [0,count) up by one, put v at 0
     if constexpr (N <= 4) {
       w = (w << 8) | (uint32_t)(v & 0xff);
+    } else if constexpr (N <= 32) {
+#pragma unroll
+      for (int k = kWords - 1; k > 0; --k) ww[k] = (ww[k] << 8) | (ww[k - 1] >> 24);
+      ww[0] = (ww[0] << 8) | (uint32_t)(v & 0xff);
     } else {
       for (int k = count; k > 0; --k) arr[k] = arr[k - 1];
       arr[0] = (uint8_t)v;
@@ -247,6 +282,10 @@ struct Env {
     const int nb = S->nb, nj = S->nj, np = S->np;
     awakeMask = 0;
     deadQ = 15u;
+    wl.clear();
+    pflags.clear();
+    toiCount.clear();
+    ic.clear();
     for (int k = 0; k < 4; ++k) {
       wallV0[k] = S->wallShape[k].v[0];
       wallV1[k] = S->wallShape[k].v[1];
@@ -1577,6 +1616,97 @@ struct Env {
     }
   }
 
+  // b2Island::SolveTOI for the mini-island {body b + its touching wall contacts ic[0..nic)} on the staged register island:
+  // up to 20 TOI position iterations, velocity constraints initialised WITH restitution and without warm starting, the
+  // velocity sweeps for the rest of the step (same bit-safe early exits as islandSolveReg), position integration.
+  // Every contact of a TOI island here is (wall, b) - other dynamic bodies are skipped when it is built (no bullets).
+  __device__ __forceinline__ void toiIslandReg(int b, int nic, float h) {
+    RegIsland<NB, NJ, kRegC> R;
+    R.nc = nic;
+    R.nj = 0;
+    R.deadQ = deadQ;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      R.pos[i].c = c[i];
+      R.pos[i].a = a[i];
+      R.vel[i].v = v[i];
+      R.vel[i].w = w[i];
+      R.mass[i].invMass = invMass[i];
+      R.mass[i].invI = invI[i];
+      R.mass[i].lc = lc[i];
+    }
+    Manifold mans[kRegC];
+#pragma unroll
+    for (int k = 0; k < kRegC; ++k) {
+      if (k < nic) {
+        int s = ic.get(k);
+        RContact& c_ = R.ct[k];
+        const Manifold m = selGet(man, s);
+        mans[k] = m;
+        slotAB(s, &c_.pA, &c_.pB);
+        c_.friction = S->pairs[s].friction;
+        c_.restitution = S->pairs[s].restitution;
+        c_.pointCount = m.pointCount;
+        c_.K.ex = c_.K.ey = V2(0.0f, 0.0f);
+        c_.normalMass.ex = c_.normalMass.ey = V2(0.0f, 0.0f);
+        c_.mtype = m.type;
+        c_.mcount = m.pointCount;
+        c_.localNormal = m.localNormal;
+        c_.localPoint = m.localPoint;
+        c_.lp0 = m.points[0].localPoint;
+        c_.lp1 = m.points[1].localPoint;
+        c_.radiusA = radiusOf(c_.pA);
+        c_.radiusB = radiusOf(c_.pB);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          RPoint& p = c_.points[j];
+          p.normalImpulse = 0.0f;
+          p.tangentImpulse = 0.0f;
+          p.rA = V2(0.0f, 0.0f);
+          p.rB = V2(0.0f, 0.0f);
+          p.normalMass = 0.0f;
+          p.tangentMass = 0.0f;
+          p.velocityBias = 0.0f;
+        }
+      }
+    }
+    for (int it = 0; it < 20; ++it) {
+      float minSeparation = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kRegC; ++k)
+        if (k < nic) minSeparation = R.template positionContact<true>(R.ct[k], minSeparation);
+      if (minSeparation >= -1.5f * kLinearSlop) break;
+    }
+    const BodyPos pb0 = rGet(R.pos, b);
+    c0[b] = pb0.c;                                   // "leap of faith to new safe state"
+    a0[b] = pb0.a;
+#pragma unroll
+    for (int k = 0; k < kRegC; ++k)
+      if (k < nic) R.initContact(R.ct[k], mans[k]);
+    R.velocitySweeps(S->velIters, h);
+    BodyPos pp = rGet(R.pos, b);
+    BodyVel vv = rGet(R.vel, b);
+    {
+      Vec2 translation = h * vv.v;
+      if (Dot(translation, translation) > kMaxTranslationSquared) {
+        float ratio = kMaxTranslation / Length(translation);
+        vv.v *= ratio;
+      }
+      float rotation = h * vv.w;
+      if (rotation * rotation > kMaxRotationSquared) {
+        float ratio = kMaxRotation / Abs(rotation);
+        vv.w *= ratio;
+      }
+      pp.c += h * vv.v;
+      pp.a += h * vv.w;
+    }
+    c[b] = pp.c;
+    a[b] = pp.a;
+    v[b] = vv.v;
+    w[b] = vv.w;
+    syncTransform(b);
+  }
+
   __device__ __forceinline__ void islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
     if constexpr (kUseReg) {
       if (nic <= kRegC) {
@@ -1917,13 +2047,15 @@ struct Env {
             else if (nv <= 4) toiWallRun<4>(&output, e0, e1, er, shB, sweepOf(pb_));
             else toiWallRun<kShapeVerts>(&output, e0, e1, er, shB, sweepOf(pb_));
           }
-#if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_SOLVE)
+#if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_SOLVE) && !defined(BLCD_PROF_TOI2)
           prof[4] += 1;
 #endif
+#ifndef BLCD_PROF_TOI2
           if (profOn && (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) {  // once per wave-level execution
             prof[6] += __builtin_amdgcn_s_memtime() - tq0;
             prof[7] += 1;
           }
+#endif
         }
         float beta = output.t;
         if (output.state == kTOITouching) alpha = Min(alpha0_ + (1.0f - alpha0_) * beta, 1.0f);
@@ -1950,6 +2082,13 @@ struct Env {
       PT(4);
       if (minSlot < 0 || 1.0f - 10.0f * kEpsilon < minAlpha) break;
 
+#ifdef BLCD_PROF_TOI2
+#define QT(k_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) prof[k_] += n_ - qt_; qt_ = n_; } while (0)
+      unsigned long long qt_ = __builtin_amdgcn_s_memtime();
+      if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) prof[7] += 1;
+#else
+#define QT(k_) do {} while (0)
+#endif
       const int wA = pairAOf(minSlot);      // wall (fixture A)
       const int pB = pairBOf(minSlot);
       const int b = bi(pB);
@@ -1975,7 +2114,8 @@ struct Env {
         continue;
       }
       wake(pB);
-#if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_SOLVE)
+      QT(0);
+#if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_SOLVE) && !defined(BLCD_PROF_TOI2)
       prof[5] += 1;
 #endif
       unsigned long long e0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
@@ -2008,8 +2148,19 @@ struct Env {
         ic.set(nic++, s);
         wallIsland |= 1u << other;
       }
+      QT(1);
       // b2Island::SolveTOI
       float h = (1.0f - minAlpha) * dt;
+      bool toiDone = false;
+      if constexpr (kUseReg) {
+        if (nic <= kRegC) {
+          QT(4);
+          toiIslandReg(b, nic, h);
+          QT(5);
+          toiDone = true;
+        }
+      }
+      if (!toiDone) {
       pc[b] = c[b];
       pa[b] = a[b];
       pv[b] = v[b];
@@ -2021,14 +2172,17 @@ struct Env {
       }
       c0[b] = pc[b];
       a0[b] = pa[b];
+      QT(4);
       csInitVelocityConstraints(nic);
       velocitySweeps(1u << b, nic, 0, h);
+      QT(5);
       integratePositions(1u << b, h);
       c[b] = pc[b];
       a[b] = pa[b];
       v[b] = pv[b];
       w[b] = pw[b];
       syncTransform(b);
+      }
       // reset island flags, synchronize the broad phase, invalidate the body's contact TOIs
       synchronizeFixtures(b);
       for (int k = 0; k < nc; ++k) {
@@ -2036,11 +2190,15 @@ struct Env {
         if (pairAOf(s) == pB || pairBOf(s) == pB) pflags.clearBits(s, PF_TOI | PF_ISLAND | PF_TOISKIP);
       }
       findNewContacts(false);
+      QT(6);
+#ifndef BLCD_PROF_TOI2
       if (profOn) prof[3] += __builtin_amdgcn_s_memtime() - e0_;
+#endif
       PT(5);
     }
     PT(5);
 #undef PT
+#undef QT
   }
 
   // b2World::Step
@@ -2067,7 +2225,7 @@ struct Env {
     if (!(skip & 4)) solveTOI(dt);
     if (profOn) {
       unsigned long long c3_ = __builtin_amdgcn_s_memtime();
-#ifndef BLCD_PROF_TOI
+#if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_TOI2)
       prof[0] += c1_ - c0_;
       prof[1] += c2_ - c1_;
 #endif

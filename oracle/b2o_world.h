@@ -131,6 +131,7 @@ struct ContactPositionConstraint {
 };
 
 struct Stats {
+  long toiIters = 0;   // diagnostic: minimum-TOI contacts advanced to (true events + those that turn out not to touch)
   long steps = 0, toiEvents = 0, toiCalls = 0, islands = 0, contactsCreated = 0, contactsDestroyed = 0;
   long sweepHist[182] = {0};
   long posIterHist[62] = {0};  // diagnostic: position iterations used per island solve (61 = not solved within the limit)
@@ -1501,6 +1502,7 @@ inline void World::SolveTOI(const TimeStep& step) {
     Body& bB = bodies[ib];
     Sweep backup1 = bA.sweep;
     Sweep backup2 = bB.sweep;
+    stats.toiIters++;
     bA.Advance(minAlpha);
     bB.Advance(minAlpha);
     UpdateContact(minContact);

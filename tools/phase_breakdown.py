@@ -23,5 +23,5 @@ for label, G in (('mixed', 0), ('64 copies per wave', 1)):
   h.rollout(a[T:], T)
   wt = h.debug_wave_times().astype(np.float64)
   ms = h.last_kernel_ms()[0]
-  print(f'{name} {label}: kernel {ms:.2f} ms / {T} env-steps; mean kcycles per wave: collide {wt[:,1].mean()/1e3:.0f} solve {wt[:,2].mean()/1e3:.0f} toi {wt[:,3].mean()/1e3:.0f} (toi-event {wt[:,4].mean()/1e3:.0f}) [prof4 {wt[:,5].mean()/1e3:.0f} prof5 {wt[:,6].mean()/1e3:.0f}]; wave ticks mean {wt[:,0].mean()*10e-6:.2f} ms max {wt[:,0].max()*10e-6:.2f} ms')
+  print(f'{name} {label}: kernel {ms:.2f} ms / {T} env-steps; mean kcycles per wave: collide {wt[:,1].mean()/1e3:.0f} solve {wt[:,2].mean()/1e3:.0f} toi {wt[:,3].mean()/1e3:.0f} (toi-event {wt[:,4].mean()/1e3:.0f}) [prof4 {wt[:,5].mean()/1e3:.0f} prof5 {wt[:,6].mean()/1e3:.0f} toi-routine {wt[:,7].mean()/1e3:.0f} kcyc in {wt[:,8].mean():.0f} wave-level runs]; wave ticks mean {wt[:,0].mean()*10e-6:.2f} ms max {wt[:,0].max()*10e-6:.2f} ms')
   h.close()
