@@ -79,6 +79,10 @@ struct RJoint {  // one revolute joint in island order
   Vec2 rA, rB;
   Mat33 mass;
   float motorMass;
+  // sweep-invariant parts of b2Mat33::Solve33 / Solve22 (the mass matrix is fixed during the velocity iterations): same
+  // expressions as upstream, evaluated once per world step instead of once per sweep
+  Vec3 cyz;          // b2Cross(ey, ez)
+  float det33, det22;  // the reciprocal determinants (0 stays 0)
 };
 
 struct RPoint {
@@ -405,6 +409,16 @@ struct RegIsland {
     Mx.ex.z = Mx.ez.x;
     Mx.ey.z = Mx.ez.y;
     Mx.ez.z = iA + iB;
+    {
+      J.cyz = Cross(Mx.ey, Mx.ez);
+      float det = Dot(Mx.ex, J.cyz);
+      if (det != 0.0f) det = 1.0f / det;
+      J.det33 = det;
+      const float a11 = Mx.ex.x, a12 = Mx.ey.x, a21 = Mx.ex.y, a22 = Mx.ey.y;
+      float d2 = a11 * a22 - a12 * a21;
+      if (d2 != 0.0f) d2 = 1.0f / d2;
+      J.det22 = d2;
+    }
     float motorMass = iA + iB;
     if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
     J.motorMass = motorMass;
@@ -461,31 +475,43 @@ struct RegIsland {
       wA -= iA * impulse;
       wB += iB * impulse;
     }
-    if (J.enableLimit && limitState != 0 && fixedRotation == false) {
-      Vec2 Cdot1 = vB + Cross(wB, rB) - vA - Cross(wA, rA);
-      float Cdot2 = wB - wA;
-      Vec3 Cdot = Vec3{Cdot1.x, Cdot1.y, Cdot2};
-      Vec3 impulse = -Mx.Solve33(Cdot);
+    {
+      // Limit and point constraint of b2RevoluteJoint::SolveVelocityConstraints as ONE predicated path.  Upstream has two
+      // branches: limit active -> 3x3 solve with the z impulse clamped (on violation: "reduced" 2x2 solve with
+      // rhs = -Cdot1 + impulse.z * ez.xy, z impulse reset to -accumulated); limit inactive -> plain 2x2 solve of -Cdot.
+      // The second branch IS the clamp case of the first with an accumulated z impulse of zero (it is zero whenever the limit
+      // is inactive): same Solve22, P applied the same way, and `+ (-0.0f)` on the angular term changes no value.  So lanes
+      // without an active limit take the clamp case (with rhs = -Cdot1 exactly), and only lanes with one run Solve33.
+      const bool lim = J.enableLimit && limitState != 0 && fixedRotation == false;
+      const Vec2 Cdot1 = vB + Cross(wB, rB) - vA - Cross(wA, rA);
       Vec3 acc = J.imp;
-      {
-        // The limit cases of b2RevoluteJoint::SolveVelocityConstraints, predicated: lanes of a wave sit in different limit
-        // states, so the branchy form ran up to five short paths one after the other.  Both candidate results are formed
-        // with the reference's expressions and one is selected per lane (equal limits: always the plain accumulation).
-        const float newImpulse = acc.z + impulse.z;
-        const bool clampCase = (limitState == 1 && newImpulse < 0.0f) || (limitState == 2 && newImpulse > 0.0f);
-        const Vec2 rhs = -Cdot1 + acc.z * V2(Mx.ez.x, Mx.ez.y);
-        const Vec2 reduced = Mx.Solve22(rhs);
-        Vec3 accPlain = acc;
-        accPlain += impulse;
-        const Vec3 impClamp = Vec3{reduced.x, reduced.y, -acc.z};
-        const Vec3 accClamp = Vec3{acc.x + reduced.x, acc.y + reduced.y, 0.0f};
-        impulse.x = clampCase ? impClamp.x : impulse.x;
-        impulse.y = clampCase ? impClamp.y : impulse.y;
-        impulse.z = clampCase ? impClamp.z : impulse.z;
-        acc.x = clampCase ? accClamp.x : accPlain.x;
-        acc.y = clampCase ? accClamp.y : accPlain.y;
-        acc.z = clampCase ? accClamp.z : accPlain.z;
+      Vec3 impulse = Vec3{0.0f, 0.0f, 0.0f};
+      if (lim) {
+        const float Cdot2 = wB - wA;
+        const Vec3 b3 = Vec3{Cdot1.x, Cdot1.y, Cdot2};
+        Vec3 x;                                   // b2Mat33::Solve33 with the hoisted Cross(ey, ez) and 1/det
+        x.x = J.det33 * Dot(b3, J.cyz);
+        x.y = J.det33 * Dot(Mx.ex, Cross(b3, Mx.ez));
+        x.z = J.det33 * Dot(Mx.ex, Cross(Mx.ey, b3));
+        impulse = -x;
       }
+      const float newImpulse = acc.z + impulse.z;
+      const bool clampCase = !lim || (limitState == 1 && newImpulse < 0.0f) || (limitState == 2 && newImpulse > 0.0f);
+      Vec2 rhs = -Cdot1;
+      if (lim) rhs = -Cdot1 + acc.z * V2(Mx.ez.x, Mx.ez.y);
+      Vec2 reduced;                               // b2Mat33::Solve22 with the hoisted 1/det
+      reduced.x = J.det22 * (Mx.ey.y * rhs.x - Mx.ey.x * rhs.y);
+      reduced.y = J.det22 * (Mx.ex.x * rhs.y - Mx.ex.y * rhs.x);
+      Vec3 accPlain = acc;
+      accPlain += impulse;
+      const Vec3 impClamp = Vec3{reduced.x, reduced.y, lim ? -acc.z : -0.0f};
+      const Vec3 accClamp = Vec3{acc.x + reduced.x, acc.y + reduced.y, lim ? 0.0f : acc.z};
+      impulse.x = clampCase ? impClamp.x : impulse.x;
+      impulse.y = clampCase ? impClamp.y : impulse.y;
+      impulse.z = clampCase ? impClamp.z : impulse.z;
+      acc.x = clampCase ? accClamp.x : accPlain.x;
+      acc.y = clampCase ? accClamp.y : accPlain.y;
+      acc.z = clampCase ? accClamp.z : accPlain.z;
       changed = changed || (impulse.x != 0.0f) || (impulse.y != 0.0f) || (impulse.z != 0.0f) || (acc.x != J.imp.x) ||
                 (acc.y != J.imp.y) || (acc.z != J.imp.z);
       J.imp = acc;
@@ -494,16 +520,6 @@ struct RegIsland {
       wA -= iA * (Cross(rA, P_) + impulse.z);
       vB += mB * P_;
       wB += iB * (Cross(rB, P_) + impulse.z);
-    } else {
-      Vec2 Cdot = vB + Cross(wB, rB) - vA - Cross(wA, rA);
-      Vec2 impulse = Mx.Solve22(-Cdot);
-      changed = changed || (impulse.x != 0.0f) || (impulse.y != 0.0f);
-      J.imp.x += impulse.x;
-      J.imp.y += impulse.y;
-      vA -= mA * impulse;
-      wA -= iA * Cross(rA, impulse);
-      vB += mB * impulse;
-      wB += iB * Cross(rB, impulse);
     }
     va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
     rSet(vel, J.A, va_);
