@@ -360,6 +360,9 @@ void b2o_period_hist(b2o_env* e, int64_t* out36) {
   out36[34] = e->world.stats.cycleAtSum;
   out36[35] = e->world.stats.cycleCount;
 }
+void b2o_pos_fix_hist(b2o_env* e, int64_t* out64) {
+  for (int i = 0; i < 64; ++i) out64[i] = e->world.stats.posFixHist[i];
+}
 int64_t b2o_toi_iters(b2o_env* e) { return e->world.stats.toiIters; }
 void b2o_pos_iter_hist(b2o_env* e, int64_t* out62) {
   for (int i = 0; i < 62; ++i) out62[i] = e->world.stats.posIterHist[i];

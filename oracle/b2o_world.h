@@ -134,6 +134,7 @@ struct Stats {
   long toiIters = 0;   // diagnostic: minimum-TOI contacts advanced to (true events + those that turn out not to touch)
   long steps = 0, toiEvents = 0, toiCalls = 0, islands = 0, contactsCreated = 0, contactsDestroyed = 0;
   long sweepHist[182] = {0};
+  long posFixHist[64] = {0};   // diagnostic: unsolved islands only - iteration at which the positions first repeat (period <= 4), 63 = never
   long posIterHist[62] = {0};  // diagnostic: position iterations used per island solve (61 = not solved within the limit)
   long periodHist[34] = {0};   // diagnostic: period (1..32) of the sweep-state cycle when one is detected, [33] = none, [0] unused
   long cycleAtSum = 0, cycleCount = 0;  // diagnostic: first velocity sweep after which the state is a fixed point (181 = never)
@@ -1269,8 +1270,19 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
   }
   bool positionSolved = false;
   int posItersUsed = 0;
+  std::vector<std::vector<Position>> posHist;
+  int posRepeatAt = -1;
   for (int i = 0; i < step.positionIterations; ++i) {
     ++posItersUsed;
+    if (stats.trackSweeps && posRepeatAt < 0) {
+      for (int pp = 1; pp <= 4 && pp <= (int)posHist.size(); ++pp) {
+        const std::vector<Position>& old = posHist[posHist.size() - pp];
+        bool same = true;
+        for (int k = 0; k < bodyCount; ++k) same = same && old[k].c.x == positions[k].c.x && old[k].c.y == positions[k].c.y && old[k].a == positions[k].a;
+        if (same) { posRepeatAt = i; break; }
+      }
+      posHist.push_back(positions);
+    }
     bool contactsOkay = contactSolver.SolvePositionConstraints();
     bool jointsOkay = true;
     for (int jid : ijoints) {
@@ -1283,6 +1295,7 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
     }
   }
   stats.posIterHist[positionSolved ? posItersUsed : 61]++;
+  if (stats.trackSweeps && !positionSolved) stats.posFixHist[posRepeatAt < 0 ? 63 : posRepeatAt]++;
   for (int i = 0; i < bodyCount; ++i) {
     Body& body = bodies[ibodies[i]];
     body.sweep.c = positions[i].c;
