@@ -20,6 +20,10 @@
 #include "blcd_toi_wall.h"
 #include "blcd_island_reg.h"
 
+#ifndef BLCD_REG_MAXNB
+#define BLCD_REG_MAXNB 7   // largest scene class that uses the staged register island (blcd_island_reg.h); see DESIGN.md §4
+#endif
+
 namespace blcd {
 
 constexpr int kMaxPairs = 100;
@@ -1419,7 +1423,7 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // register-resident island solve (blcd_island_reg.h) for multi-body scenes: islands with <= kRegC contacts
   // ------------------------------------------------------------------------------------------------
-  static constexpr bool kUseReg = (NB > 1) && (NB <= 5) && (NJ <= 4);   // beyond 5 bodies the staged island no longer fits the register file (991 spills at NB = 7)
+  static constexpr bool kUseReg = (NB > 1) && (NB <= BLCD_REG_MAXNB) && (NJ <= 4);   // NB = 7: re-enabled in round 2 (parity incl. a -ftrivial-auto-var-init=pattern build; UrchinBalls +26 %), see DESIGN.md
   static constexpr int kRegC = 4;
   __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
     const int nb = S->nb;
