@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES = {'Dropbox': 564, 'Bounce': 564, 'Object2': 924, 'Urchin': 1836, 'LuxoBall': 2236}
 HBM_PEAK_GBS = 8000.0                                                                            # MI355X_MICROARCH.md
-RASTER_NAMES = {0: 'pillow-9.0.x (inferred)', 1: 'pillow-12.2 (goldens)', 2: 'recording era (GIF frames)'}
+RASTER_NAMES = {0: 'pillow-9.0.x (inferred, no fixture)', 1: 'pillow-12.2 (goldens)', 2: "recordings' Pillow (default; pinned by the reference's GIF frames)"}
 # HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes (separate --pmc runs) of the default workload;
 # only quoted when the run uses that workload with default knobs.
 TRAFFIC_PROFILE = 'profiles/r02_bounce100k_pmc.json'
