@@ -212,7 +212,7 @@ def main():
         'config': {'workload': f'envs.{args.env}() {d.lcd_h}x{d.lcd_w}, {N} envs/GPU, one step = {args.rollouts_per_step} rollouts of {T} env-steps '
                                'from reset, U(-1,1) actions, obs + LCD rendered every env-step', 'envs_per_gpu': N, 'rollout_len': T,
                    'rollouts_per_step': args.rollouts_per_step, 'parallelism': f'env-sharded x{world}',
-                   'collective': None if world == 1 else f'all-gather of every chunk\'s lcd[{w.chunk},{N},{d.lcd_h},{d.lcd_w}] u8 + full_state[{w.chunk},{N},{d.n_obs}] f32 on a side stream',
+                   'collective': None if world == 1 else f'all-gather of every chunk\'s lcd[{w.chunk},{N},{d.lcd_h},{d.lcd_w}] u8 (1 bit per pixel on the wire, delivered as u8) + full_state[{w.chunk},{N},{d.n_obs}] f32 on a side stream',
                    'raster_variant': RASTER_NAMES.get(w.venv.raster_variant, str(w.venv.raster_variant)), 'overrides': overrides,
                    'faulted_envs': faults, 'awake_fraction_at_end': awake_frac},
         'roofline': roof,

@@ -28,6 +28,8 @@ SYMBOLS = {
     'blcd_render_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'blcd_set_ellipse_rgb_lut': (C.c_int, [C.c_void_p, C.c_int32]),
     'blcd_render_poses_ex': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    'blcd_pack_bits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'blcd_unpack_bits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'blcd_get_poses': (C.c_int, [C.c_void_p, C.c_void_p]),
     'blcd_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
     'blcd_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -73,6 +75,15 @@ def load():
   if lib.blcd_set_ellipse_rgb_lut(lut.ctypes.data_as(C.c_void_p), amax) != 0:
     raise RuntimeError('blcd_set_ellipse_rgb_lut failed')
   return lib
+
+
+def pack_bits(src, dst, stream_ptr=None):
+  """uint8 0/1 CUDA tensor -> packed CUDA tensor (numel/8 bytes), asynchronously on the given hipStream_t"""
+  _check(load().blcd_pack_bits(src.data_ptr(), dst.data_ptr(), src.numel(), stream_ptr))
+
+
+def unpack_bits(src, dst, stream_ptr=None):
+  _check(load().blcd_unpack_bits(src.data_ptr(), dst.data_ptr(), dst.numel(), stream_ptr))
 
 
 class EnvFaultError(RuntimeError):

@@ -1143,6 +1143,38 @@ static int goal_launch(blcd_handle h, const int* dIdx, int n, int seedOnly, doub
   return BLCD_OK;
 }
 
+// ---- 1-bit transport of LCD frames (the frames are bool arrays; eight pixels travel as one byte) -----------
+__global__ void pack_bits_kernel(const uint2* __restrict__ src, uint8_t* __restrict__ dst, long long n8) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint2 v = src[i];   // 8 pixels, one byte each (0 / 1); bit k of the result = pixel k
+  const uint32_t lo = ((v.x & 0x01010101u) * 0x10204080u) >> 28, hi = ((v.y & 0x01010101u) * 0x10204080u) >> 28;
+  dst[i] = (uint8_t)(lo | (hi << 4));
+}
+__global__ void unpack_bits_kernel(const uint8_t* __restrict__ src, uint2* __restrict__ dst, long long n8) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint32_t b = src[i];
+  uint2 v;
+  v.x = ((b & 0xfu) * 0x00204081u) & 0x01010101u;
+  v.y = ((b >> 4) * 0x00204081u) & 0x01010101u;
+  dst[i] = v;
+}
+int blcd_pack_bits(const uint8_t* src, uint8_t* dst, int64_t n_pixels, void* stream) {
+  if (!src || !dst || n_pixels < 8 || (n_pixels & 7) || ((uintptr_t)src & 7)) return fail(BLCD_ERR_INVALID, "blcd_pack_bits: bad arguments");
+  const long long n8 = n_pixels / 8;
+  hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint2*)src, dst, n8);
+  HIPCHK(hipGetLastError());
+  return BLCD_OK;
+}
+int blcd_unpack_bits(const uint8_t* src, uint8_t* dst, int64_t n_pixels, void* stream) {
+  if (!src || !dst || n_pixels < 8 || (n_pixels & 7) || ((uintptr_t)dst & 7)) return fail(BLCD_ERR_INVALID, "blcd_unpack_bits: bad arguments");
+  const long long n8 = n_pixels / 8;
+  hipLaunchKernelGGL(unpack_bits_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (uint2*)dst, n8);
+  HIPCHK(hipGetLastError());
+  return BLCD_OK;
+}
+
 // ---- lcd_render(width, height, lcd_mode) --------------------------------------------------------------------------
 static std::vector<uint8_t> g_lutHost;   // process-wide: Pillow's ellipse fill/outline span table (DATA, boxlcd_amd/ellipse_rgb_lut.bin)
 static int g_lutAmax = -1;

@@ -56,18 +56,24 @@ class ChunkGatherer:
   preallocated `[world, Tc, N, ...]` buffers, on a side stream so that the next chunk's stepping overlaps the transfer.
 
   Equal shards (the bench's weak-scaling layout) go through `all_gather_into_tensor` straight into the destination - no
-  pad, no concatenate.  Destination buffers are double-buffered; collectives are ordered by the side stream, so a buffer is
-  only rewritten after the gather that last filled it has finished.  `producer` is the stream the chunk was written on
-  (the handle's stream); the returned event marks the end of the gather: make the producer wait on it before it rewrites
-  the source region (`producer.wait_event(ev)`)."""
+  pad, no concatenate.  uint8 0/1 tensors (LCD frames: the reference's bool arrays) cross the links at ONE BIT per pixel
+  (`blcd_pack_bits` before, `blcd_unpack_bits` after the collective, both on the side stream) and are delivered as uint8
+  again - 8x less xGMI traffic for the tensor that is 94 % of a chunk.  Destination buffers are double-buffered; collectives
+  are ordered by the side stream, so a buffer is only rewritten after the gather that last filled it has finished.
+  `producer` is the stream the chunk was written on (the handle's stream); the returned event marks the end of the gather:
+  make the producer wait on it before it rewrites the source region (`producer.wait_event(ev)`)."""
 
-  def __init__(self, world, templates, nbuf=2):
+  def __init__(self, world, templates, nbuf=2, pack_bits=True):
     import torch
     self.world = world
     self.cuda = templates[0].is_cuda
     self.bufs = [[torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in templates] for _ in range(nbuf)]
     self.k = 0
     self.stream = torch.cuda.Stream(device=templates[0].device) if self.cuda else None
+    # packed staging for the uint8 tensors (GPU only: the kernels live in the HIP library)
+    self.packed = [self.cuda and pack_bits and t.dtype == torch.uint8 and t.numel() % 8 == 0 for t in templates]
+    self.pk_src = [torch.empty(t.numel() // 8, dtype=torch.uint8, device=t.device) if p else None for t, p in zip(templates, self.packed)]
+    self.pk_dst = [torch.empty(world * t.numel() // 8, dtype=torch.uint8, device=t.device) if p else None for t, p in zip(templates, self.packed)]
 
   def gather(self, srcs, producer=None):
     import torch
@@ -78,12 +84,19 @@ class ChunkGatherer:
       for d, s in zip(dst, srcs):
         dist.all_gather(list(d.unbind(0)), s.contiguous())
       return None
+    from . import _lib
     ready = torch.cuda.Event()
     ready.record(producer if producer is not None else torch.cuda.current_stream())
     with torch.cuda.stream(self.stream):
       self.stream.wait_event(ready)
-      for d, s in zip(dst, srcs):
-        dist.all_gather_into_tensor(d.flatten(0, 1), s)   # [world*Tc, N, ...] = concatenation along dim 0 (NCCL and gloo)
+      sp = self.stream.cuda_stream
+      for i, (d, s) in enumerate(zip(dst, srcs)):
+        if self.packed[i]:
+          _lib.pack_bits(s, self.pk_src[i], sp)
+          dist.all_gather_into_tensor(self.pk_dst[i], self.pk_src[i])
+          _lib.unpack_bits(self.pk_dst[i], d, sp)
+        else:
+          dist.all_gather_into_tensor(d.flatten(0, 1), s)   # [world*Tc, N, ...] = concatenation along dim 0 (NCCL and gloo)
       done = torch.cuda.Event()
       done.record(self.stream)
     return done

@@ -180,6 +180,13 @@ int blcd_set_ellipse_rgb_lut(const uint8_t* lut /* host */, int32_t amax);
 int blcd_render_poses_ex(blcd_handle h, const float* poses, const int32_t* shape_sel, int32_t m, int32_t width, int32_t height,
                          int32_t mode, uint8_t* out);
 
+/* Transport form of LCD frames (the reference's frames are bool arrays, world_env.py:506-509): n_pixels 0/1
+ * bytes <-> n_pixels/8 bytes, bit k of byte i = pixel 8i+k.  Device pointers, asynchronous on `stream` (a hipStream_t; NULL =
+ * the default stream); n_pixels a multiple of 8, the byte-per-pixel buffer 8-byte aligned.  Used by the multi-GPU gather
+ * (boxlcd_amd/dist.py) so that rollouts cross xGMI at one bit per pixel and are delivered as uint8 again. */
+int blcd_pack_bits(const uint8_t* src, uint8_t* dst, int64_t n_pixels, void* stream);
+int blcd_unpack_bits(const uint8_t* src, uint8_t* dst, int64_t n_pixels, void* stream);
+
 /* Body poses for host-side consumers: float32 [n_envs][n_bodies][4] = transform.position.x, .y, body.angle, awake. */
 int blcd_get_poses(blcd_handle h, float* poses);
 

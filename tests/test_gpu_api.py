@@ -191,3 +191,59 @@ def test_device_resident_vector_env():
   b.reset(idx.numpy())
   assert (o['full_state'].cpu().numpy() == b._obs()['full_state']).all()
   a.close(); b.close()
+
+
+def test_bit_transport_of_lcd_frames():
+  """blcd_pack_bits / blcd_unpack_bits (the 1-bit wire format of the multi-GPU gather): exact round trip, numpy bit order."""
+  import torch
+  from boxlcd_amd import _lib
+  _lib.load()
+  x = (torch.rand((7, 33, 16, 24), device='cuda') < 0.3).to(torch.uint8)
+  p = torch.empty(x.numel() // 8, dtype=torch.uint8, device='cuda')
+  y = torch.empty_like(x)
+  s = torch.cuda.current_stream().cuda_stream
+  _lib.pack_bits(x, p, s)
+  _lib.unpack_bits(p, y, s)
+  torch.cuda.synchronize()
+  assert (x == y).all()
+  assert (p.cpu().numpy() == np.packbits(x.cpu().numpy().reshape(-1), bitorder='little')).all()
+
+
+def _gather_rank(rank, world, port, q):
+  import os, torch
+  from boxlcd_amd import dist as bdist
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  bdist.init_from_env('gloo')                      # both ranks share cuda:0 here; on a node it is nccl, one GPU per rank
+  torch.cuda.set_device(0)
+  Tc, n = 4, 96
+  g = bdist.ChunkGatherer(world, [torch.empty((Tc, n, 16, 16), dtype=torch.uint8, device='cuda'), torch.empty((Tc, n, 4), device='cuda')])
+  ok = True
+  for chunk in range(3):
+    gen = torch.Generator(device='cuda'); gen.manual_seed(100 * chunk + rank)
+    lcd = (torch.rand((Tc, n, 16, 16), device='cuda', generator=gen) < 0.4).to(torch.uint8)
+    obs = torch.rand((Tc, n, 4), device='cuda', generator=gen)
+    g.gather([lcd, obs], producer=torch.cuda.current_stream())
+    g.finish()
+    gl, go = g.last()
+    for r in range(world):
+      gen2 = torch.Generator(device='cuda'); gen2.manual_seed(100 * chunk + r)
+      el = (torch.rand((Tc, n, 16, 16), device='cuda', generator=gen2) < 0.4).to(torch.uint8)
+      eo = torch.rand((Tc, n, 4), device='cuda', generator=gen2)
+      ok = ok and bool((gl[r] == el).all()) and bool((go[r] == eo).all())
+  q.put((rank, ok))
+  torch.distributed.destroy_process_group()
+
+
+def test_chunk_gather_of_full_rollout_tensors_two_ranks():
+  """The N>1 data path of bench.py --gpus N: every rank receives every rank's full chunk tensors; LCD frames travel at one bit
+  per pixel and arrive as uint8.  Two processes on this one GPU (gloo); on a node the same code runs over RCCL."""
+  import socket
+  import torch.multiprocessing as mp
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_gather_rank, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs: p.start()
+  res = [q.get(timeout=240) for _ in procs]
+  for p in procs: p.join(timeout=60)
+  assert sorted(res) == [(0, True), (1, True)]
