@@ -1,10 +1,9 @@
-"""Host-side helpers with the semantics of the reference's `boxLCD/utils.py` (AttrDict :5-7, args_type :9-16,
-A[...] :18-31, NamedArray :33-101, dict/list filters :104-112, make_rot :115, mapto :117, rmapto :119).
+"""Host-side helpers the hot path uses, with the semantics of the reference's `boxLCD/utils.py` (AttrDict :5-7,
+A[...] :18-31, NamedArray :33-101, sortdict/nfiltlist :104-111, mapto :117, rmapto :119).
 
 The arithmetic of `mapto` / `rmapto` is part of the hot path's contract (observation normalisation and the
 action -> motorSpeed mapping): float64, in exactly this operation order.
 """
-import pathlib
 import re
 import numpy as np
 
@@ -13,17 +12,6 @@ class AttrDict(dict):
   """dict whose items are also attributes (reference utils.py:5-7)."""
   __setattr__ = dict.__setitem__
   __getattr__ = dict.__getitem__
-
-
-def args_type(default):
-  """argparse `type=` factory keyed on the default's Python type (reference utils.py:9-16)."""
-  if isinstance(default, bool):
-    return lambda x: bool(['False', 'True'].index(x))
-  if isinstance(default, int):
-    return lambda x: float(x) if ('e' in x or '.' in x) else int(x)
-  if isinstance(default, pathlib.Path):
-    return lambda x: pathlib.Path(x).expanduser()
-  return type(default)
 
 
 class _ArrayMaker:
@@ -87,12 +75,5 @@ class NamedArray:
       raise NotImplementedError
 
 
-def subdict(d, subkeys): return {key: d[key] for key in subkeys}
-def sortdict(x): return subdict(x, sorted(x))
-def subdlist(d, subkeys): return [d[key] for key in subkeys]
-def filtdict(d, phrase): return {k: d[k] for k in d if re.match(phrase, k) is not None}
-def nfiltdict(d, phrase): return {k: d[k] for k in d if re.match(phrase, k) is None}
-def filtlist(l, phrase): return [i for i in l if re.match(phrase, i) is not None]
+def sortdict(x): return {key: x[key] for key in sorted(x)}
 def nfiltlist(l, phrase): return [i for i in l if re.match(phrase, i) is None]
-def get_angle(sin, cos): return np.arctan2(sin, cos)
-def make_rot(angle): return A[[np.cos(angle), -np.sin(angle)], [np.sin(angle), np.cos(angle)]]
