@@ -102,43 +102,123 @@ struct RContact {  // velocity + position constraint of one contact in island or
   float radiusA, radiusB;
 };
 
-template <int NB, int NJR, int NCR>
+// Body rows (velocity, position, mass data) are addressed with run-time body ids.  Two homes for them:
+//  * LDS = false: small register arrays behind compare-select chains (1-2 selects per word for 2-3 bodies);
+//  * LDS = true : the wave's LDS block, laid out [word][lane] (word = 10 * body + field, 64 lanes per word: every access is
+//    bank-conflict free whatever body each lane asks for).  For >= 4 bodies this replaces ~550 v_cndmask, ~260
+//    v_readlane/v_writelane (hoisted compare masks spilling out of the SGPR file) and part of the AGPR shuffling per
+//    velocity sweep by a handful of ds_read/ds_write (ISA of the (4,3,16) class), and frees 10 * NB VGPRs.
+// Pure data movement either way: the arithmetic is untouched.
+template <int NB, int NJR, int NCR, bool LDS = false>
 struct RegIsland {
-  BodyVel vel[NB];
-  BodyPos pos[NB];
-  BodyMass mass[NB];
+  static constexpr int kBodyWords = 10;   // v.x v.y w | c.x c.y a | invMass invI lc.x lc.y
+  static constexpr int kLdsWords = kBodyWords * NB * 64;
+  BodyVel vel[LDS ? 1 : NB];
+  BodyPos pos[LDS ? 1 : NB];
+  BodyMass mass[LDS ? 1 : NB];
+  float* L;        // LDS mode: this lane's column of the block (word k at L[64 * k])
   RJoint jt[NJR > 0 ? NJR : 1];
   RContact ct[NCR];
   int nj, nc;
   uint32_t deadQ;  // Env::deadQ
 
-  // ---- body accessors by proxy id ----
+  // ---- body rows by dynamic-body index ----
+  __device__ __forceinline__ BodyVel getVel(int i) const {
+    if constexpr (LDS) {
+      const float* q = L + 64 * kBodyWords * i;
+      BodyVel r;
+      r.v.x = q[0];
+      r.v.y = q[64];
+      r.w = q[128];
+      return r;
+    } else {
+      return rGet(vel, i);
+    }
+  }
+  __device__ __forceinline__ void setVel(int i, const BodyVel& x) {
+    if constexpr (LDS) {
+      float* q = L + 64 * kBodyWords * i;
+      q[0] = x.v.x;
+      q[64] = x.v.y;
+      q[128] = x.w;
+    } else {
+      rSet(vel, i, x);
+    }
+  }
+  __device__ __forceinline__ BodyPos getPos(int i) const {
+    if constexpr (LDS) {
+      const float* q = L + 64 * (kBodyWords * i + 3);
+      BodyPos r;
+      r.c.x = q[0];
+      r.c.y = q[64];
+      r.a = q[128];
+      return r;
+    } else {
+      return rGet(pos, i);
+    }
+  }
+  __device__ __forceinline__ void setPos(int i, const BodyPos& x) {
+    if constexpr (LDS) {
+      float* q = L + 64 * (kBodyWords * i + 3);
+      q[0] = x.c.x;
+      q[64] = x.c.y;
+      q[128] = x.a;
+    } else {
+      rSet(pos, i, x);
+    }
+  }
+  __device__ __forceinline__ BodyMass getMass(int i) const {
+    if constexpr (LDS) {
+      const float* q = L + 64 * (kBodyWords * i + 6);
+      BodyMass r;
+      r.invMass = q[0];
+      r.invI = q[64];
+      r.lc.x = q[128];
+      r.lc.y = q[192];
+      return r;
+    } else {
+      return rGet(mass, i);
+    }
+  }
+  __device__ __forceinline__ void setMass(int i, const BodyMass& x) {
+    if constexpr (LDS) {
+      float* q = L + 64 * (kBodyWords * i + 6);
+      q[0] = x.invMass;
+      q[64] = x.invI;
+      q[128] = x.lc.x;
+      q[192] = x.lc.y;
+    } else {
+      rSet(mass, i, x);
+    }
+  }
+
+  // ---- body accessors by proxy id (0..3 = the static walls: zero rows, writes dropped) ----
   __device__ __forceinline__ BodyVel V(int p) const {
     BodyVel z;
     z.v = V2(0.0f, 0.0f);
     z.w = 0.0f;
-    BodyVel r = rGet(vel, p < 4 ? 0 : p - 4);
+    BodyVel r = getVel(p < 4 ? 0 : p - 4);
     return p < 4 ? z : r;
   }
   __device__ __forceinline__ void setV(int p, const BodyVel& x) {
-    if (p >= 4) rSet(vel, p - 4, x);
+    if (p >= 4) setVel(p - 4, x);
   }
   __device__ __forceinline__ BodyPos P(int p) const {
     BodyPos z;
     z.c = V2(0.0f, 0.0f);
     z.a = 0.0f;
-    BodyPos r = rGet(pos, p < 4 ? 0 : p - 4);
+    BodyPos r = getPos(p < 4 ? 0 : p - 4);
     return p < 4 ? z : r;
   }
   __device__ __forceinline__ void setP(int p, const BodyPos& x) {
-    if (p >= 4) rSet(pos, p - 4, x);
+    if (p >= 4) setPos(p - 4, x);
   }
   __device__ __forceinline__ BodyMass M(int p) const {
     BodyMass z;
     z.invMass = 0.0f;
     z.invI = 0.0f;
     z.lc = V2(0.0f, 0.0f);
-    BodyMass r = rGet(mass, p < 4 ? 0 : p - 4);
+    BodyMass r = getMass(p < 4 ? 0 : p - 4);
     return p < 4 ? z : r;
   }
 
@@ -387,9 +467,9 @@ struct RegIsland {
 
   // ---- b2RevoluteJoint ----
   __device__ __forceinline__ void initJoint(RJoint& J, float dtRatio) {
-    BodyMass mAs = rGet(mass, J.A), mBs = rGet(mass, J.B);
-    BodyPos pa_ = rGet(pos, J.A), pb_ = rGet(pos, J.B);
-    BodyVel va_ = rGet(vel, J.A), vb_ = rGet(vel, J.B);
+    BodyMass mAs = getMass(J.A), mBs = getMass(J.B);
+    BodyPos pa_ = getPos(J.A), pb_ = getPos(J.B);
+    BodyVel va_ = getVel(J.A), vb_ = getVel(J.B);
     float aA = pa_.a, aB = pb_.a;
     Vec2 vA = va_.v, vB = vb_.v;
     float wA = va_.w, wB = vb_.w;
@@ -449,14 +529,14 @@ struct RegIsland {
     vB += mB * P_;
     wB += iB * (Cross(rB, P_) + J.motor + J.imp.z);
     va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
-    rSet(vel, J.A, va_);
-    rSet(vel, J.B, vb_);
+    setVel(J.A, va_);
+    setVel(J.B, vb_);
   }
 
   __device__ __forceinline__ bool sweepJoint(RJoint& J, float dt) {
     bool changed = false;
-    BodyMass mAs = rGet(mass, J.A), mBs = rGet(mass, J.B);
-    BodyVel va_ = rGet(vel, J.A), vb_ = rGet(vel, J.B);
+    BodyMass mAs = getMass(J.A), mBs = getMass(J.B);
+    BodyVel va_ = getVel(J.A), vb_ = getVel(J.B);
     Vec2 vA = va_.v, vB = vb_.v;
     float wA = va_.w, wB = vb_.w;
     float mA = mAs.invMass, mB = mBs.invMass, iA = mAs.invI, iB = mBs.invI;
@@ -522,14 +602,14 @@ struct RegIsland {
       wB += iB * (Cross(rB, P_) + impulse.z);
     }
     va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
-    rSet(vel, J.A, va_);
-    rSet(vel, J.B, vb_);
+    setVel(J.A, va_);
+    setVel(J.B, vb_);
     return changed;
   }
 
   __device__ __forceinline__ bool positionJoint(const RJoint& J) {
-    BodyMass mAs = rGet(mass, J.A), mBs = rGet(mass, J.B);
-    BodyPos pa_ = rGet(pos, J.A), pb_ = rGet(pos, J.B);
+    BodyMass mAs = getMass(J.A), mBs = getMass(J.B);
+    BodyPos pa_ = getPos(J.A), pb_ = getPos(J.B);
     Vec2 cA = pa_.c, cB = pb_.c;
     float aA = pa_.a, aB = pb_.a;
     float mA = mAs.invMass, mB = mBs.invMass, iA = mAs.invI, iB = mBs.invI;
@@ -576,8 +656,8 @@ struct RegIsland {
       aB += iB * Cross(rB, impulse);
     }
     pa_.c = cA; pa_.a = aA; pb_.c = cB; pb_.a = aB;
-    rSet(pos, J.A, pa_);
-    rSet(pos, J.B, pb_);
+    setPos(J.A, pa_);
+    setPos(J.B, pb_);
     return positionError <= kLinearSlop && angularError <= kAngularSlop;
   }
 
@@ -590,9 +670,10 @@ struct RegIsland {
   __device__ __forceinline__ void cycPack(CycRow& r) const {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      r.v[3 * i] = vel[i].v.x;
-      r.v[3 * i + 1] = vel[i].v.y;
-      r.v[3 * i + 2] = vel[i].w;
+      const BodyVel bv = getVel(i);
+      r.v[3 * i] = bv.v.x;
+      r.v[3 * i + 1] = bv.v.y;
+      r.v[3 * i + 2] = bv.w;
     }
 #pragma unroll
     for (int k = 0; k < NCR; ++k)
@@ -606,9 +687,11 @@ struct RegIsland {
   __device__ __forceinline__ void cycUnpack(const CycRow& r) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      vel[i].v.x = r.v[3 * i];
-      vel[i].v.y = r.v[3 * i + 1];
-      vel[i].w = r.v[3 * i + 2];
+      BodyVel bv;
+      bv.v.x = r.v[3 * i];
+      bv.v.y = r.v[3 * i + 1];
+      bv.w = r.v[3 * i + 2];
+      setVel(i, bv);
     }
 #pragma unroll
     for (int k = 0; k < NCR; ++k)

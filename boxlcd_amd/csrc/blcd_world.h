@@ -23,6 +23,9 @@
 #ifndef BLCD_REG_MAXNB
 #define BLCD_REG_MAXNB 7   // largest scene class that uses the staged register island (blcd_island_reg.h); see DESIGN.md §4
 #endif
+#ifndef BLCD_REG_LDS
+#define BLCD_REG_LDS 1     // classes with >= 4 bodies keep the staged island's body rows in LDS instead of select chains
+#endif
 
 namespace blcd {
 
@@ -1425,10 +1428,23 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   static constexpr bool kUseReg = (NB > 1) && (NB <= BLCD_REG_MAXNB) && (NJ <= 4);   // NB = 7: re-enabled in round 2 (parity incl. a -ftrivial-auto-var-init=pattern build; UrchinBalls +26 %), see DESIGN.md
   static constexpr int kRegC = 4;
+  static constexpr bool kRegLds = BLCD_REG_LDS && NB >= 4;   // body rows of the staged island live in LDS (see RegIsland)
+  using RegI = RegIsland<NB, NJ, kRegC, kRegLds>;
+  // this lane's column of the wave's staged-island LDS block (one block per kernel: the main solve and the TOI
+  // mini-islands never overlap in time)
+  __device__ __forceinline__ float* regIslandLds() {
+    if constexpr (kRegLds) {
+      __shared__ float blk[RegI::kLdsWords];
+      return blk + threadIdx.x;
+    } else {
+      return nullptr;
+    }
+  }
   __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
     const int nb = S->nb;
     Vec2 gravity = S->gravity;
-    RegIsland<NB, NJ, kRegC> R;
+    RegI R;
+    R.L = regIslandLds();
     R.nc = nic;
     R.nj = nij;
     R.deadQ = deadQ;
@@ -1445,13 +1461,9 @@ struct Env {
         v_ *= Clamp(1.0f - h * S->bodies[i].linearDamping, 0.0f, 1.0f);    // Box2D 2.3.0 (first-order; >= 2.3.1 is Pade)
         w_ *= Clamp(1.0f - h * S->bodies[i].angularDamping, 0.0f, 1.0f);
       }
-      R.pos[i].c = c[i];
-      R.pos[i].a = a[i];
-      R.vel[i].v = v_;
-      R.vel[i].w = w_;
-      R.mass[i].invMass = invMass[i];
-      R.mass[i].invI = invI[i];
-      R.mass[i].lc = lc[i];
+      R.setPos(i, BodyPos{c[i], a[i]});
+      R.setVel(i, BodyVel{v_, w_});
+      R.setMass(i, BodyMass{invMass[i], invI[i], lc[i]});
     }
     // contacts in island order: b2ContactSolver ctor + InitializeVelocityConstraints
     Manifold mans[kRegC];
@@ -1546,10 +1558,12 @@ struct Env {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       if (i < nb && ((ibmask >> i) & 1)) {
-        Vec2 c_ = R.pos[i].c;
-        float a_ = R.pos[i].a;
-        Vec2 v_ = R.vel[i].v;
-        float w_ = R.vel[i].w;
+        const BodyPos bp_ = R.getPos(i);
+        const BodyVel bv_ = R.getVel(i);
+        Vec2 c_ = bp_.c;
+        float a_ = bp_.a;
+        Vec2 v_ = bv_.v;
+        float w_ = bv_.w;
         Vec2 translation = h * v_;
         if (Dot(translation, translation) > kMaxTranslationSquared) {
           float ratio = kMaxTranslation / Length(translation);
@@ -1562,10 +1576,8 @@ struct Env {
         }
         c_ += h * v_;
         a_ += h * w_;
-        R.pos[i].c = c_;
-        R.pos[i].a = a_;
-        R.vel[i].v = v_;
-        R.vel[i].w = w_;
+        R.setPos(i, BodyPos{c_, a_});
+        R.setVel(i, BodyVel{v_, w_});
       }
     }
     int pit = 0;
@@ -1580,10 +1592,12 @@ struct Env {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       if (i < nb && ((ibmask >> i) & 1)) {
-        c[i] = R.pos[i].c;
-        a[i] = R.pos[i].a;
-        v[i] = R.vel[i].v;
-        w[i] = R.vel[i].w;
+        const BodyPos bp_ = R.getPos(i);
+        const BodyVel bv_ = R.getVel(i);
+        c[i] = bp_.c;
+        a[i] = bp_.a;
+        v[i] = bv_.v;
+        w[i] = bv_.w;
         syncTransform(i);
       }
     }
@@ -1625,19 +1639,16 @@ struct Env {
   // velocity sweeps for the rest of the step (same bit-safe early exits as islandSolveReg), position integration.
   // Every contact of a TOI island here is (wall, b) - other dynamic bodies are skipped when it is built (no bullets).
   __device__ __forceinline__ void toiIslandReg(int b, int nic, float h) {
-    RegIsland<NB, NJ, kRegC> R;
+    RegI R;
+    R.L = regIslandLds();
     R.nc = nic;
     R.nj = 0;
     R.deadQ = deadQ;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      R.pos[i].c = c[i];
-      R.pos[i].a = a[i];
-      R.vel[i].v = v[i];
-      R.vel[i].w = w[i];
-      R.mass[i].invMass = invMass[i];
-      R.mass[i].invI = invI[i];
-      R.mass[i].lc = lc[i];
+      R.setPos(i, BodyPos{c[i], a[i]});
+      R.setVel(i, BodyVel{v[i], w[i]});
+      R.setMass(i, BodyMass{invMass[i], invI[i], lc[i]});
     }
     Manifold mans[kRegC];
 #pragma unroll
@@ -1681,15 +1692,15 @@ struct Env {
         if (k < nic) minSeparation = R.template positionContact<true>(R.ct[k], minSeparation);
       if (minSeparation >= -1.5f * kLinearSlop) break;
     }
-    const BodyPos pb0 = rGet(R.pos, b);
+    const BodyPos pb0 = R.getPos(b);
     c0[b] = pb0.c;                                   // "leap of faith to new safe state"
     a0[b] = pb0.a;
 #pragma unroll
     for (int k = 0; k < kRegC; ++k)
       if (k < nic) R.initContact(R.ct[k], mans[k]);
     R.velocitySweeps(S->velIters, h);
-    BodyPos pp = rGet(R.pos, b);
-    BodyVel vv = rGet(R.vel, b);
+    BodyPos pp = R.getPos(b);
+    BodyVel vv = R.getVel(b);
     {
       Vec2 translation = h * vv.v;
       if (Dot(translation, translation) > kMaxTranslationSquared) {

@@ -163,3 +163,31 @@ def test_goal_wrapper_column_selection():
   assert cube.keys == ['object0:x:p', 'object0:y:p'] and [env.obs_keys[i] for i in cube.root_idxs] == ['urchin0:root:x:p', 'urchin0:root:y:p']
   assert set(body.observation_space.spaces) >= {'goal:lcd', 'goal:proprio'}
   assert cube.observation_space.spaces['goal:object'].shape == (2,)
+
+
+def test_step_kernel_isa_passes_the_exec_restore_scan(tmp_path):
+  """Guard against a ROCm 7.2 clang miscompile of the 512-VGPR step kernels: a join block that saves an outer
+  register (AGPR write / spill store) BEFORE restoring its own exec mask.  build() keeps each class's device ISA
+  (csrc/_obj/cfg_*/...s) and rebuilds a flagged class with the workaround; here the scanner is checked on a synthetic hit
+  and every kept ISA file must be clean."""
+  import sys
+  import __graft_entry__ as G
+  sys.path.insert(0, os.path.join(G.ROOT, 'tools'))
+  import scan_endcf
+  bad = tmp_path / 'bad.s'
+  bad.write_text('\n'.join([
+      '\tv_add_u32_e32 v131, 24, v40', '\ts_and_saveexec_b64 s[0:1], s[16:17]', '\ts_cbranch_execz .LBB1_2', '; %bb.1:',
+      '\tv_mov_b32_e32 v14, 6', '.LBB1_2:', '\tv_accvgpr_write_b32 a43, v131', '\ts_or_b64 exec, exec, s[0:1]', '\ts_endpgm']))
+  assert len(scan_endcf.scan(str(bad))) == 1
+  good = tmp_path / 'good.s'
+  good.write_text(bad.read_text().replace('\tv_accvgpr_write_b32 a43, v131\n\ts_or_b64 exec, exec, s[0:1]',
+                                           '\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a43, v131'))
+  assert scan_endcf.scan(str(good)) == []
+  objdir = os.path.join(G.ROOT, 'boxlcd_amd', 'csrc', '_obj')
+  isas = [os.path.join(objdir, d, 'blcd_cfg-hip-amdgcn-amd-amdhsa-gfx950.s') for d in sorted(os.listdir(objdir)) if d.startswith('cfg_')] \
+      if os.path.isdir(objdir) else []
+  isas = [p for p in isas if os.path.exists(p)]
+  if not isas:
+    pytest.skip('no kept ISA (library was built elsewhere)')
+  for p in isas:
+    assert scan_endcf.scan(p) == [], p
