@@ -109,10 +109,17 @@ struct RContact {  // velocity + position constraint of one contact in island or
 //    v_readlane/v_writelane (hoisted compare masks spilling out of the SGPR file) and part of the AGPR shuffling per
 //    velocity sweep by a handful of ds_read/ds_write (ISA of the (4,3,16) class), and frees 10 * NB VGPRs.
 // Pure data movement either way: the arithmetic is untouched.
-template <int NB, int NJR, int NCR, bool LDS = false>
+//  * CLDS = true (with LDS): the sweep-invariant part of every contact's velocity constraint (lever arms, effective masses,
+//    bias, normal, block matrices: 23 words per contact) is parked in a second LDS block [word][lane] with compile-time
+//    offsets, and only the accumulated impulses stay in registers.  The hot set of a 3-joint + 4-contact island is ~260
+//    words against 256 VGPRs, so without this ~400 v_accvgpr moves per sweep shuttle it through the AGPR half.
+template <int NB, int NJR, int NCR, bool LDS = false, bool CLDS = false>
 struct RegIsland {
   static constexpr int kBodyWords = 10;   // v.x v.y w | c.x c.y a | invMass invI lc.x lc.y
   static constexpr int kLdsWords = kBodyWords * NB * 64;
+  static constexpr int kCtWords = 23;     // per point {rA rB normalMass tangentMass velocityBias} x2 | normal | normalMass(3) | K(3) | friction
+  static constexpr int kCtLdsWords = kCtWords * NCR * 64;
+  float* C;        // CLDS mode: this lane's column of the contact-constant block
   BodyVel vel[LDS ? 1 : NB];
   BodyPos pos[LDS ? 1 : NB];
   BodyMass mass[LDS ? 1 : NB];
@@ -222,8 +229,87 @@ struct RegIsland {
     return p < 4 ? z : r;
   }
 
+  // sweep-invariant velocity-constraint data of one contact (b2ContactVelocityConstraint minus the accumulated impulses)
+  struct SweepC {
+    Vec2 rA[2], rB[2];
+    float normalMass[2], tangentMass[2], velocityBias[2];
+    Vec2 normal;
+    Mat22 nm, K;
+    float friction;
+  };
+  __device__ __forceinline__ SweepC loadSweepC(int k, const RContact& c_) const {
+    SweepC q;
+    if constexpr (CLDS) {
+      const float* p = C + 64 * kCtWords * k;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        q.rA[j] = V2(p[64 * (7 * j)], p[64 * (7 * j + 1)]);
+        q.rB[j] = V2(p[64 * (7 * j + 2)], p[64 * (7 * j + 3)]);
+        q.normalMass[j] = p[64 * (7 * j + 4)];
+        q.tangentMass[j] = p[64 * (7 * j + 5)];
+        q.velocityBias[j] = p[64 * (7 * j + 6)];
+      }
+      q.normal = V2(p[64 * 14], p[64 * 15]);
+      q.nm.ex = V2(p[64 * 16], p[64 * 17]);
+      q.nm.ey = V2(p[64 * 17], p[64 * 18]);     // inverse of a symmetric matrix: ex.y == ey.x bit for bit (b2Mat22::GetInverse)
+      q.K.ex = V2(p[64 * 19], p[64 * 20]);
+      q.K.ey = V2(p[64 * 20], p[64 * 21]);
+      q.friction = p[64 * 22];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        q.rA[j] = c_.points[j].rA;
+        q.rB[j] = c_.points[j].rB;
+        q.normalMass[j] = c_.points[j].normalMass;
+        q.tangentMass[j] = c_.points[j].tangentMass;
+        q.velocityBias[j] = c_.points[j].velocityBias;
+      }
+      q.normal = c_.normal;
+      q.nm = c_.normalMass;
+      q.K = c_.K;
+      q.friction = c_.friction;
+    }
+    return q;
+  }
+  __device__ __forceinline__ void storeSweepC(int k, RContact& c_, const SweepC& q) {
+    if constexpr (CLDS) {
+      float* p = C + 64 * kCtWords * k;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        p[64 * (7 * j)] = q.rA[j].x;
+        p[64 * (7 * j + 1)] = q.rA[j].y;
+        p[64 * (7 * j + 2)] = q.rB[j].x;
+        p[64 * (7 * j + 3)] = q.rB[j].y;
+        p[64 * (7 * j + 4)] = q.normalMass[j];
+        p[64 * (7 * j + 5)] = q.tangentMass[j];
+        p[64 * (7 * j + 6)] = q.velocityBias[j];
+      }
+      p[64 * 14] = q.normal.x;
+      p[64 * 15] = q.normal.y;
+      p[64 * 16] = q.nm.ex.x;
+      p[64 * 17] = q.nm.ex.y;
+      p[64 * 18] = q.nm.ey.y;
+      p[64 * 19] = q.K.ex.x;
+      p[64 * 20] = q.K.ex.y;
+      p[64 * 21] = q.K.ey.y;
+      p[64 * 22] = q.friction;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        c_.points[j].rA = q.rA[j];
+        c_.points[j].rB = q.rB[j];
+        c_.points[j].normalMass = q.normalMass[j];
+        c_.points[j].tangentMass = q.tangentMass[j];
+        c_.points[j].velocityBias = q.velocityBias[j];
+      }
+      c_.normal = q.normal;
+      c_.normalMass = q.nm;
+      c_.K = q.K;
+    }
+  }
+
   // ---- b2ContactSolver::InitializeVelocityConstraints for contact k (k static) ----
-  __device__ __forceinline__ void initContact(RContact& c_, const Manifold& manifold) {
+  __device__ __forceinline__ void initContact(int k, RContact& c_, const Manifold& manifold) {
     const int pA = c_.pA, pB = c_.pB;
     BodyMass mAs = M(pA), mBs = M(pB);
     float mA = mAs.invMass, mB = mBs.invMass, iA = mAs.invI, iB = mBs.invI;
@@ -238,64 +324,72 @@ struct RegIsland {
     xfB.p = cB - Mul(xfB.q, mBs.lc);
     WorldManifold worldManifold;
     worldManifold.Initialize(&manifold, xfA, c_.radiusA, xfB, c_.radiusB);
-    c_.normal = worldManifold.normal;
+    SweepC q;
+    q.normal = worldManifold.normal;
+    q.friction = c_.friction;
+    q.K.ex = q.K.ey = V2(0.0f, 0.0f);
+    q.nm.ex = q.nm.ey = V2(0.0f, 0.0f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      q.rA[j] = q.rB[j] = V2(0.0f, 0.0f);
+      q.normalMass[j] = q.tangentMass[j] = q.velocityBias[j] = 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (j >= c_.pointCount) break;
-      RPoint* vcp = c_.points + j;
-      vcp->rA = worldManifold.points[j] - cA;
-      vcp->rB = worldManifold.points[j] - cB;
-      float rnA = Cross(vcp->rA, c_.normal);
-      float rnB = Cross(vcp->rB, c_.normal);
+      q.rA[j] = worldManifold.points[j] - cA;
+      q.rB[j] = worldManifold.points[j] - cB;
+      float rnA = Cross(q.rA[j], q.normal);
+      float rnB = Cross(q.rB[j], q.normal);
       float kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
-      vcp->normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
-      Vec2 tangent = Cross(c_.normal, 1.0f);
-      float rtA = Cross(vcp->rA, tangent);
-      float rtB = Cross(vcp->rB, tangent);
+      q.normalMass[j] = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+      Vec2 tangent = Cross(q.normal, 1.0f);
+      float rtA = Cross(q.rA[j], tangent);
+      float rtB = Cross(q.rB[j], tangent);
       float kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
-      vcp->tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
-      vcp->velocityBias = 0.0f;
-      float vRel = Dot(c_.normal, vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA));
-      if (vRel < -kVelocityThreshold) vcp->velocityBias = -c_.restitution * vRel;
+      q.tangentMass[j] = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+      q.velocityBias[j] = 0.0f;
+      float vRel = Dot(q.normal, vB + Cross(wB, q.rB[j]) - vA - Cross(wA, q.rA[j]));
+      if (vRel < -kVelocityThreshold) q.velocityBias[j] = -c_.restitution * vRel;
     }
     if (c_.pointCount == 2) {
-      RPoint* vcp1 = c_.points + 0;
-      RPoint* vcp2 = c_.points + 1;
-      float rn1A = Cross(vcp1->rA, c_.normal);
-      float rn1B = Cross(vcp1->rB, c_.normal);
-      float rn2A = Cross(vcp2->rA, c_.normal);
-      float rn2B = Cross(vcp2->rB, c_.normal);
+      float rn1A = Cross(q.rA[0], q.normal);
+      float rn1B = Cross(q.rB[0], q.normal);
+      float rn2A = Cross(q.rA[1], q.normal);
+      float rn2B = Cross(q.rB[1], q.normal);
       float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
       float k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
       float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
       const float k_maxConditionNumber = 1000.0f;
       if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
-        c_.K.ex = V2(k11, k12);
-        c_.K.ey = V2(k12, k22);
-        c_.normalMass = c_.K.GetInverse();
+        q.K.ex = V2(k11, k12);
+        q.K.ey = V2(k12, k22);
+        q.nm = q.K.GetInverse();
       } else {
         c_.pointCount = 1;
       }
     }
+    storeSweepC(k, c_, q);
   }
 
-  __device__ __forceinline__ void warmStartContact(RContact& c_) {
+  __device__ __forceinline__ void warmStartContact(int k, RContact& c_) {
     const int pA = c_.pA, pB = c_.pB;
+    const SweepC q = loadSweepC(k, c_);
     BodyMass mAs = M(pA), mBs = M(pB);
     float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
     BodyVel va_ = V(pA), vb_ = V(pB);
     Vec2 vA = va_.v, vB = vb_.v;
     float wA = va_.w, wB = vb_.w;
-    Vec2 normal = c_.normal;
+    Vec2 normal = q.normal;
     Vec2 tangent = Cross(normal, 1.0f);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (j >= c_.pointCount) break;
       RPoint* vcp = c_.points + j;
       Vec2 P_ = vcp->normalImpulse * normal + vcp->tangentImpulse * tangent;
-      wA -= iA * Cross(vcp->rA, P_);
+      wA -= iA * Cross(q.rA[j], P_);
       vA -= mA * P_;
-      wB += iB * Cross(vcp->rB, P_);
+      wB += iB * Cross(q.rB[j], P_);
       vB += mB * P_;
     }
     va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
@@ -304,25 +398,26 @@ struct RegIsland {
   }
 
   // b2ContactSolver::SolveVelocityConstraints for one contact; returns true iff a non-zero impulse was applied
-  __device__ __forceinline__ bool sweepContact(RContact& c_) {
+  __device__ __forceinline__ bool sweepContact(int k, RContact& c_) {
     bool changed = false;
     const int pA = c_.pA, pB = c_.pB;
+    const SweepC q = loadSweepC(k, c_);
     BodyMass mAs = M(pA), mBs = M(pB);
     float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
     int pointCount = c_.pointCount;
     BodyVel va_ = V(pA), vb_ = V(pB);
     Vec2 vA = va_.v, vB = vb_.v;
     float wA = va_.w, wB = vb_.w;
-    Vec2 normal = c_.normal;
+    Vec2 normal = q.normal;
     Vec2 tangent = Cross(normal, 1.0f);
-    float friction = c_.friction;
+    float friction = q.friction;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (j >= pointCount) break;
       RPoint* vcp = c_.points + j;
-      Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+      Vec2 dv = vB + Cross(wB, q.rB[j]) - vA - Cross(wA, q.rA[j]);
       float vt = Dot(dv, tangent) - 0.0f;
-      float lambda = vcp->tangentMass * (-vt);
+      float lambda = q.tangentMass[j] * (-vt);
       float maxFriction = friction * vcp->normalImpulse;
       float newImpulse = Clamp(vcp->tangentImpulse + lambda, -maxFriction, maxFriction);
       lambda = newImpulse - vcp->tangentImpulse;
@@ -330,50 +425,50 @@ struct RegIsland {
       changed = changed || (lambda != 0.0f);
       Vec2 P_ = lambda * tangent;
       vA -= mA * P_;
-      wA -= iA * Cross(vcp->rA, P_);
+      wA -= iA * Cross(q.rA[j], P_);
       vB += mB * P_;
-      wB += iB * Cross(vcp->rB, P_);
+      wB += iB * Cross(q.rB[j], P_);
     }
     if (pointCount == 1) {
       RPoint* vcp = c_.points + 0;
-      Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+      Vec2 dv = vB + Cross(wB, q.rB[0]) - vA - Cross(wA, q.rA[0]);
       float vn = Dot(dv, normal);
-      float lambda = -vcp->normalMass * (vn - vcp->velocityBias);
+      float lambda = -q.normalMass[0] * (vn - q.velocityBias[0]);
       float newImpulse = Max(vcp->normalImpulse + lambda, 0.0f);
       lambda = newImpulse - vcp->normalImpulse;
       vcp->normalImpulse = newImpulse;
       changed = changed || (lambda != 0.0f);
       Vec2 P_ = lambda * normal;
       vA -= mA * P_;
-      wA -= iA * Cross(vcp->rA, P_);
+      wA -= iA * Cross(q.rA[0], P_);
       vB += mB * P_;
-      wB += iB * Cross(vcp->rB, P_);
+      wB += iB * Cross(q.rB[0], P_);
     } else {
       RPoint* cp1 = c_.points + 0;
       RPoint* cp2 = c_.points + 1;
       Vec2 a_ = V2(cp1->normalImpulse, cp2->normalImpulse);
-      Vec2 dv1 = vB + Cross(wB, cp1->rB) - vA - Cross(wA, cp1->rA);
-      Vec2 dv2 = vB + Cross(wB, cp2->rB) - vA - Cross(wA, cp2->rA);
+      Vec2 dv1 = vB + Cross(wB, q.rB[0]) - vA - Cross(wA, q.rA[0]);
+      Vec2 dv2 = vB + Cross(wB, q.rB[1]) - vA - Cross(wA, q.rA[1]);
       float vn1 = Dot(dv1, normal);
       float vn2 = Dot(dv2, normal);
       Vec2 b;
-      b.x = vn1 - cp1->velocityBias;
-      b.y = vn2 - cp2->velocityBias;
-      b -= Mul(c_.K, a_);
+      b.x = vn1 - q.velocityBias[0];
+      b.y = vn2 - q.velocityBias[1];
+      b -= Mul(q.K, a_);
       Vec2 x;
       bool solved = false;
-      x = -Mul(c_.normalMass, b);
+      x = -Mul(q.nm, b);
       if (x.x >= 0.0f && x.y >= 0.0f) solved = true;
       if (!solved) {
-        x.x = -cp1->normalMass * b.x;
+        x.x = -q.normalMass[0] * b.x;
         x.y = 0.0f;
-        vn2 = c_.K.ex.y * x.x + b.y;
+        vn2 = q.K.ex.y * x.x + b.y;
         if (x.x >= 0.0f && vn2 >= 0.0f) solved = true;
       }
       if (!solved) {
         x.x = 0.0f;
-        x.y = -cp2->normalMass * b.y;
-        vn1 = c_.K.ey.x * x.y + b.x;
+        x.y = -q.normalMass[1] * b.y;
+        vn1 = q.K.ey.x * x.y + b.x;
         if (x.y >= 0.0f && vn1 >= 0.0f) solved = true;
       }
       if (!solved) {
@@ -389,9 +484,9 @@ struct RegIsland {
         Vec2 P1 = d.x * normal;
         Vec2 P2 = d.y * normal;
         vA -= mA * (P1 + P2);
-        wA -= iA * (Cross(cp1->rA, P1) + Cross(cp2->rA, P2));
+        wA -= iA * (Cross(q.rA[0], P1) + Cross(q.rA[1], P2));
         vB += mB * (P1 + P2);
-        wB += iB * (Cross(cp1->rB, P1) + Cross(cp2->rB, P2));
+        wB += iB * (Cross(q.rB[0], P1) + Cross(q.rB[1], P2));
         cp1->normalImpulse = x.x;
         cp2->normalImpulse = x.y;
       }
@@ -717,7 +812,7 @@ struct RegIsland {
       }
 #pragma unroll
       for (int k = 0; k < NCR; ++k)
-        if (k < nc) changed = sweepContact(ct[k]) || changed;
+        if (k < nc) changed = sweepContact(k, ct[k]) || changed;
       ++done;
       if (!changed) break;
       if (watch && it < 24) {

@@ -26,6 +26,9 @@
 #ifndef BLCD_REG_LDS
 #define BLCD_REG_LDS 1     // classes with >= 4 bodies keep the staged island's body rows in LDS instead of select chains
 #endif
+#ifndef BLCD_REG_CLDS
+#define BLCD_REG_CLDS 1    // ... and (<= 5 bodies) the contacts' sweep-invariant constants too
+#endif
 
 namespace blcd {
 
@@ -1429,7 +1432,8 @@ struct Env {
   static constexpr bool kUseReg = (NB > 1) && (NB <= BLCD_REG_MAXNB) && (NJ <= 4);   // NB = 7: re-enabled in round 2 (parity incl. a -ftrivial-auto-var-init=pattern build; UrchinBalls +26 %), see DESIGN.md
   static constexpr int kRegC = 4;
   static constexpr bool kRegLds = BLCD_REG_LDS && NB >= 4;   // body rows of the staged island live in LDS (see RegIsland)
-  using RegI = RegIsland<NB, NJ, kRegC, kRegLds>;
+  static constexpr bool kRegCtLds = kRegLds && BLCD_REG_CLDS && NB <= 5;   // + the contacts' sweep constants (LDS budget: 4 waves per CU)
+  using RegI = RegIsland<NB, NJ, kRegC, kRegLds, kRegCtLds>;
   // this lane's column of the wave's staged-island LDS block (one block per kernel: the main solve and the TOI
   // mini-islands never overlap in time)
   __device__ __forceinline__ float* regIslandLds() {
@@ -1440,11 +1444,20 @@ struct Env {
       return nullptr;
     }
   }
+  __device__ __forceinline__ float* regContactLds() {
+    if constexpr (kRegCtLds) {
+      __shared__ float blk[RegI::kCtLdsWords];
+      return blk + threadIdx.x;
+    } else {
+      return nullptr;
+    }
+  }
   __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
     const int nb = S->nb;
     Vec2 gravity = S->gravity;
     RegI R;
     R.L = regIslandLds();
+    R.C = regContactLds();
     R.nc = nic;
     R.nj = nij;
     R.deadQ = deadQ;
@@ -1503,10 +1516,10 @@ struct Env {
     }
 #pragma unroll
     for (int k = 0; k < kRegC; ++k)
-      if (k < nic) R.initContact(R.ct[k], mans[k]);
+      if (k < nic) R.initContact(k, R.ct[k], mans[k]);
 #pragma unroll
     for (int k = 0; k < kRegC; ++k)
-      if (k < nic) R.warmStartContact(R.ct[k]);
+      if (k < nic) R.warmStartContact(k, R.ct[k]);
     if constexpr (NJ > 0) {
 #pragma unroll
       for (int k = 0; k < NJ; ++k) {
@@ -1641,6 +1654,7 @@ struct Env {
   __device__ __forceinline__ void toiIslandReg(int b, int nic, float h) {
     RegI R;
     R.L = regIslandLds();
+    R.C = regContactLds();
     R.nc = nic;
     R.nj = 0;
     R.deadQ = deadQ;
@@ -1697,7 +1711,7 @@ struct Env {
     a0[b] = pb0.a;
 #pragma unroll
     for (int k = 0; k < kRegC; ++k)
-      if (k < nic) R.initContact(R.ct[k], mans[k]);
+      if (k < nic) R.initContact(k, R.ct[k], mans[k]);
     R.velocitySweeps(S->velIters, h);
     BodyPos pp = R.getPos(b);
     BodyVel vv = R.getVel(b);
