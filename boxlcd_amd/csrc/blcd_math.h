@@ -82,15 +82,18 @@ BLCD_HD static inline double sc_cos_poly(double t2) {             // 1 + t^2 (C0
 #define BLCD_SINCOS_ATTR __attribute__((noinline))
 #endif
 BLCD_HD static BLCD_SINCOS_ATTR void blcd_sincosf(float y, float* sinp, float* cosp) {
+  // Same bits as the table-driven routine, with its argument ranges folded so that a wave whose lanes hold angles from
+  // different ranges runs ONE polynomial pass instead of three:
+  //  * [2^-5, pi/4) is the reduced path with n = 1, k = 0 (t = |y| - 0 = |y| exactly; the odd sine polynomial commutes with
+  //    the sign, which is then applied from signbit(y) like everywhere else);
+  //  * the two reductions ([pi/4, 9pi/4): one table constant; beyond: hi/lo parts) become a select.
+  // Only |y| < 2^-5 (short polynomials / tiny arguments) and |y| >= 2^23 keep their own (rare) branches.
   const double kPio4 = 0x1.921fb54442d18p-1, kPio2 = 0x1.921fb54442d18p+0;
   const double theta = y;
   const double a = theta < 0.0 ? -theta : theta;
-  if (a < kPio4) {
+  if (a < 0x1p-5) {
     const double t2 = theta * theta;
-    if (a >= 0x1p-5) {
-      *sinp = (float)sc_sin_poly(theta, t2);
-      *cosp = (float)sc_cos_poly(t2);
-    } else if (a >= 0x1p-27) {
+    if (a >= 0x1p-27) {
       *sinp = (float)(theta + theta * t2 * (-0x1.555555543d49dp-3 + t2 * 0x1.110f475cec8c5p-7));
       *cosp = (float)(1.0 + t2 * (-0x1.fffffff5cc6fdp-2 + t2 * 0x1.55514b178dac5p-5));
     } else {
@@ -103,11 +106,11 @@ BLCD_HD static BLCD_SINCOS_ATTR void blcd_sincosf(float y, float* sinp, float* c
     *sinp = *cosp = y - y;
     return;
   }
-  const unsigned n = (unsigned)(a * 0x1.45f306dc9c883p+0) + 1u;     // |y| * 4/pi, +1
+  const unsigned n = (unsigned)(a * 0x1.45f306dc9c883p+0) + 1u;     // |y| * 4/pi, +1  (1 below pi/4)
   const double k = (double)(n >> 1);
-  double t;
-  if (a < 9 * kPio4) t = a - k * kPio2;                              // pio2_table[n / 2]
-  else t = (a - k * 0x1.921fb544p+0) - k * 0x1.0b4611a626332p-34;   // PI_2_hi, PI_2_lo
+  const double tNear = a - k * kPio2;                                            // pio2_table[n / 2]
+  const double tFar = (a - k * 0x1.921fb544p+0) - k * 0x1.0b4611a626332p-34;     // PI_2_hi, PI_2_lo
+  const double t = a < 9 * kPio4 ? tNear : tFar;
   const double t2 = t * t;
   const double sp = sc_sin_poly(t, t2), cp = sc_cos_poly(t2);
   // sinf: polynomial by (n & 2), sign by ((n >> 2) & 1) ^ signbit; cosf: the same with n + 2 and no signbit

@@ -28,7 +28,14 @@ def test_rest_of_catalogue_bit_exact(name):
 
 def test_device_sincos_equals_oracle():
   rng = np.random.RandomState(0)
-  x = np.concatenate([rng.uniform(-130, 130, 1 << 20), rng.uniform(-1e-2, 1e-2, 4096), rng.uniform(-1e6, 1e6, 4096),
+  # every float within 2 000 ulps of each range boundary of the routine (the device folds some ranges into one pass)
+  edges = []
+  for t in (2.0 ** -27, 2.0 ** -5, np.pi / 4, 9 * np.pi / 4, 2.0 ** 23):
+    u = np.float32(t).view(np.uint32)
+    w = (u + np.arange(-2000, 2001)).astype(np.uint32).view(np.float32)
+    edges += [w, -w]
+  x = np.concatenate([rng.uniform(-130, 130, 1 << 20), rng.uniform(-1, 1, 1 << 18), rng.uniform(-1e-2, 1e-2, 4096),
+                      rng.uniform(-1e6, 1e6, 4096), np.concatenate(edges),
                       [0.0, -0.0, 0.75, 0.7853982, 119.99, 120.0, 1e9]]).astype(np.float32)
   from boxlcd_amd import _lib
   s, c = np.zeros_like(x), np.zeros_like(x)
