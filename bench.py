@@ -226,9 +226,10 @@ def main():
   del w
   torch.cuda.empty_cache()
   if rank == 0 and world == 1 and not args.no_configs and args.env == 'Bounce':
-    # the other single-GPU BASELINE workloads, driver-run: north_star's Dropbox-100k target and configs[2] Urchin-50k
+    # the other BASELINE workloads, driver-run on this one GPU: north_star's Dropbox-100k target, configs[2] Urchin-50k, and the
+    # whole batches of configs[3] LuxoBall-50k and configs[4] Object2-200k (they fit one MI355X)
     cfgs = {}
-    for name, n_envs, rolls in (('Dropbox', 100000, 20), ('Urchin', 50000, 3)):
+    for name, n_envs, rolls in (('Dropbox', 100000, 20), ('Urchin', 50000, 3), ('LuxoBall', 50000, 2), ('Object2', 200000, 2)):
       ww = Workload(name, n_envs, T, local, dev, seed=1000)
       sec = time_rollouts(ww, rolls, 1, bdist, torch)
       cfgs[f'{name}-{n_envs}'] = {'value': rolls * T * n_envs / sec, 'unit': 'env-steps/s', 'rollouts': rolls, 'seconds': sec,
