@@ -1033,7 +1033,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     h->evPool.push_back(ev);
   }
   int nLaunch = 0;
-  if (h->hostScene.lcdH == 16 && h->rolloutChunk > 0) {
+  if ((h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0) {
     // fused path: `chunk` env steps per launch, every wave runs its envs through the whole chunk and emits obs/LCD itself;
     // slots are re-binned by work class between chunks
     for (int t = 0; t < T; t += h->rolloutChunk) {

@@ -75,8 +75,12 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
           }
           __builtin_amdgcn_wave_barrier();
         } else {
-          ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr,
-                                                      lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr);
+          float* obsRowOut = obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr;
+          uint8_t* lcdRowOut = lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr;
+          bool tall = false;
+          if constexpr (NB > 7) tall = S->lcdH == 32;   // 32-row LCDs (Crab, CrabCube, SpiderCube) only occur in the largest class
+          if (tall) ok = emit_env<32, uint64_t, float, false>(S, body, obsRowOut, lcdRowOut);
+          else ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowOut, lcdRowOut);
         }
         if (!ok) env.fault |= FAULT_ELLIPSE;
       }
