@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0                                                           
 RASTER_NAMES = {0: 'pillow-9.0.x (inferred, no fixture)', 1: 'pillow-12.2 (goldens)', 2: "recordings' Pillow (default; pinned by the reference's GIF frames)"}
 # HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes (separate --pmc runs) of the default workload;
 # only quoted when the run uses that workload with default knobs.
-TRAFFIC_PROFILE = 'profiles/r02_bounce100k_pmc.json'
+TRAFFIC_PROFILE = 'profiles/r02b_bounce100k_pmc.json'
 
 
 def cpu_baseline(env_name, T, target_s=12.0):
