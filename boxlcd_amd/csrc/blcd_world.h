@@ -1814,6 +1814,54 @@ struct Env {
     }
   }
 
+  // island discovery of b2World::Solve from one seed body: depth-first over contact edges (world contact-list order filtered
+  // by body) then joint edges; fills ic[0..nic) / ij[0..nij) in island order and marks what it visited
+  __device__ __forceinline__ void islandDFS(int seed, uint32_t& bodyIsland, uint32_t& jointIsland, uint32_t& ibmask, int& nic, int& nij) {
+    int stack[NB + 4];
+    uint32_t wallIsland = 0;
+    int sp = 0;
+    stack[sp++] = 4 + seed;
+    bodyIsland |= 1u << seed;
+    while (sp > 0) {
+      int p = stack[--sp];
+      if (p < 4) continue;  // static bodies join the island but are not expanded
+      int b = p - 4;
+      ibmask |= 1u << b;
+      wake(p);
+      for (int k = 0; k < nc; ++k) {  // contact-edge list of b == world list filtered by b (same relative order)
+        int s = wl.get(k);
+        int pa_ = pairAOf(s), pb_ = pairBOf(s);
+        if (pa_ != p && pb_ != p) continue;
+        int fl = pflags.get(s);
+        if (fl & PF_ISLAND) continue;
+        if (!(fl & PF_ENABLED) || !(fl & PF_TOUCHING)) continue;
+        ic.set(nic++, s);
+        pflags.set(s, fl | PF_ISLAND);
+        int other = pa_ == p ? pb_ : pa_;
+        if (other < 4) {
+          if ((wallIsland >> other) & 1) continue;
+          wallIsland |= 1u << other;
+          stack[sp++] = other;
+        } else {
+          if ((bodyIsland >> (other - 4)) & 1) continue;
+          bodyIsland |= 1u << (other - 4);
+          stack[sp++] = other;
+        }
+      }
+      const DevBody& db = S->bodies[b];
+      for (int k = 0; k < db.nJoints; ++k) {
+        int j = db.joints[k];
+        if ((jointIsland >> j) & 1) continue;
+        int other = S->joints[j].bodyA == b ? S->joints[j].bodyB : S->joints[j].bodyA;
+        ij[nij++] = (uint8_t)j;
+        jointIsland |= 1u << j;
+        if ((bodyIsland >> other) & 1) continue;
+        bodyIsland |= 1u << other;
+        stack[sp++] = 4 + other;
+      }
+    }
+  }
+
   // b2World::Solve
   __device__ __forceinline__ void solve(float h, float dtRatio) {
     if constexpr (NB == 1) {
@@ -1841,54 +1889,49 @@ struct Env {
     const int nb = S->nb;
     uint32_t bodyIsland = 0, jointIsland = 0;
     for (int k = 0; k < nc; ++k) pflags.clearBits(wl.get(k), PF_ISLAND);
-    int stack[NB + 4];
-    for (int seed = NB - 1; seed >= 0; --seed) {
-      if (seed >= nb) continue;
-      if ((bodyIsland >> seed) & 1) continue;
-      if (!awakeDyn(seed)) continue;
-      uint32_t ibmask = 0, wallIsland = 0;
-      int nic = 0, nij = 0, sp = 0;
-      stack[sp++] = 4 + seed;
-      bodyIsland |= 1u << seed;
-      while (sp > 0) {
-        int p = stack[--sp];
-        if (p < 4) continue;  // static bodies join the island but are not expanded
-        int b = p - 4;
-        ibmask |= 1u << b;
-        wake(p);
-        for (int k = 0; k < nc; ++k) {  // contact-edge list of b == world list filtered by b (same relative order)
-          int s = wl.get(k);
-          int pa_ = pairAOf(s), pb_ = pairBOf(s);
-          if (pa_ != p && pb_ != p) continue;
-          int fl = pflags.get(s);
-          if (fl & PF_ISLAND) continue;
-          if (!(fl & PF_ENABLED) || !(fl & PF_TOUCHING)) continue;
-          ic.set(nic++, s);
-          pflags.set(s, fl | PF_ISLAND);
-          int other = pa_ == p ? pb_ : pa_;
-          if (other < 4) {
-            if ((wallIsland >> other) & 1) continue;
-            wallIsland |= 1u << other;
-            stack[sp++] = other;
-          } else {
-            if ((bodyIsland >> (other - 4)) & 1) continue;
-            bodyIsland |= 1u << (other - 4);
-            stack[sp++] = other;
-          }
-        }
-        const DevBody& db = S->bodies[b];
-        for (int k = 0; k < db.nJoints; ++k) {
-          int j = db.joints[k];
-          if ((jointIsland >> j) & 1) continue;
-          int other = S->joints[j].bodyA == b ? S->joints[j].bodyB : S->joints[j].bodyA;
-          ij[nij++] = (uint8_t)j;
-          jointIsland |= 1u << j;
-          if ((bodyIsland >> other) & 1) continue;
-          bodyIsland |= 1u << other;
-          stack[sp++] = 4 + other;
+    if constexpr (NJ > 0) {
+      // Islands are disjoint, so the ORDER in which they are solved changes nothing - but in a wave it decides whether the
+      // lanes' expensive (jointed) islands run in the same loop iteration.  With the seed loop alone, an environment whose
+      // free object touches the robot solves the robot at the object's seed and its neighbour lane solves it one seed later:
+      // the wave pays the 180 jointed sweeps twice.  So: discover first (each island keeps Box2D's own seed = its first body
+      // in body-list order, hence its own DFS order), then solve the jointed islands of all lanes together, then the rest.
+      uint32_t jointedSeeds = 0, plainSeeds = 0;
+      for (int seed = NB - 1; seed >= 0; --seed) {
+        if (seed >= nb) continue;
+        if ((bodyIsland >> seed) & 1) continue;
+        if (!awakeDyn(seed)) continue;
+        uint32_t ibmask = 0;
+        int nic = 0, nij = 0;
+        islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
+        if (nij > 0) jointedSeeds |= 1u << seed;
+        else plainSeeds |= 1u << seed;
+      }
+      for (int k = 0; k < nc; ++k) pflags.clearBits(wl.get(k), PF_ISLAND);
+      const uint32_t allBodies = bodyIsland;
+      bodyIsland = 0;
+      jointIsland = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        uint32_t seeds = pass == 0 ? jointedSeeds : plainSeeds;
+        while (seeds) {
+          const int seed = 31 - __clz((int)seeds);   // body-list order = descending index
+          seeds &= ~(1u << seed);
+          uint32_t ibmask = 0;
+          int nic = 0, nij = 0;
+          islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
+          islandSolve(ibmask, nic, nij, h, dtRatio);
         }
       }
-      islandSolve(ibmask, nic, nij, h, dtRatio);
+      bodyIsland = allBodies;
+    } else {
+      for (int seed = NB - 1; seed >= 0; --seed) {
+        if (seed >= nb) continue;
+        if ((bodyIsland >> seed) & 1) continue;
+        if (!awakeDyn(seed)) continue;
+        uint32_t ibmask = 0;
+        int nic = 0, nij = 0;
+        islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
+        islandSolve(ibmask, nic, nij, h, dtRatio);
+      }
     }
     for (int i = NB - 1; i >= 0; --i) {
       if (i >= nb) continue;
