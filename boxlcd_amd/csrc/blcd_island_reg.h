@@ -799,12 +799,15 @@ struct RegIsland {
   }
 
   // all velocity sweeps, with the bit-safe early exits of the generic path (fixed point; short cycle for joint-free islands)
-  __device__ __forceinline__ int velocitySweeps(int velIters, float dt) {
+  __device__ __forceinline__ int velocitySweeps(int velIters, float dt, unsigned long long* waveIters = nullptr) {
     int done = 0;
     const bool watch = nj == 0 && nc > 0;
     CycRow cyc[kCycP];
     for (int it = 0; it < velIters; ++it) {
       bool changed = false;
+#ifdef BLCD_PROF_TOI2
+      if (waveIters && (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) *waveIters += 1;   // wave-level iterations
+#endif
       if constexpr (NJR > 0) {
 #pragma unroll
         for (int k = 0; k < NJR; ++k)

@@ -1699,20 +1699,34 @@ struct Env {
         }
       }
     }
+#ifdef BLCD_PROF_TOI2
+    unsigned long long qa_ = __builtin_amdgcn_s_memtime();
+    const bool qrec_ = (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1;
+#endif
     for (int it = 0; it < 20; ++it) {
       float minSeparation = 0.0f;
 #pragma unroll
       for (int k = 0; k < kRegC; ++k)
         if (k < nic) minSeparation = R.template positionContact<true>(R.ct[k], minSeparation);
       if (minSeparation >= -1.5f * kLinearSlop) break;
+#ifdef BLCD_PROF_TOI2
+#endif
     }
+#ifdef BLCD_PROF_TOI2
+    { unsigned long long qb_ = __builtin_amdgcn_s_memtime(); if (qrec_) prof[3] += qb_ - qa_; }
+#endif
     const BodyPos pb0 = R.getPos(b);
     c0[b] = pb0.c;                                   // "leap of faith to new safe state"
     a0[b] = pb0.a;
 #pragma unroll
     for (int k = 0; k < kRegC; ++k)
       if (k < nic) R.initContact(k, R.ct[k], mans[k]);
+#ifdef BLCD_PROF_TOI2
+    R.velocitySweeps(S->velIters, h, &prof[7]);
+    if (qrec_) prof[4] += 1000;   // event rounds (x1000: the tool prints thousands)
+#else
     R.velocitySweeps(S->velIters, h);
+#endif
     BodyPos pp = R.getPos(b);
     BodyVel vv = R.getVel(b);
     {
