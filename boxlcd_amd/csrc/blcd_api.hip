@@ -555,6 +555,8 @@ struct blcd_handle_s {
   uint8_t *goalLcd = nullptr, *goalCurLcd = nullptr;
   int binMode = 1;          // work_class: 0 generic classes only, 1 impact-time sorting for one-body scenes (BLCD_BINMODE)
   int rolloutChunk = 20;    // env steps per fused rollout launch (BLCD_CHUNK; 0 = one launch per step + separate obs kernel)
+  bool chunkFixed = false;  // BLCD_CHUNK given: no adaptation
+  float estMsPerStep = 0.0f;  // step-kernel time per env step of the last fused rollout (sizes the chunks of jointed scenes)
   unsigned long long* waveTimes = nullptr;  // per-wave duration of the last step launch (diagnostic, BLCD_WAVETIMES=1)
   int stepsSinceRebin = 0;
   size_t words = 0;
@@ -894,7 +896,10 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   if (const char* ev = getenv("BLCD_BINMODE")) h->binMode = atoi(ev);
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
   if (getenv("BLCD_WAVETIMES")) HIPCHK(hipMalloc((void**)&h->waveTimes, (size_t)n_envs * 9 * sizeof(unsigned long long)));
-  if (const char* ev = getenv("BLCD_CHUNK")) h->rolloutChunk = atoi(ev);
+  if (const char* ev = getenv("BLCD_CHUNK")) {
+    h->rolloutChunk = atoi(ev);
+    h->chunkFixed = true;
+  }
   {
     // Environments per wave.  A wave costs the UNION of its lanes' code paths (which contact slots exist, 1- or 2-point
     // manifolds, limit states, position iterations up to the slowest lane), and these kernels run one wave per SIMD, so when
@@ -1032,12 +1037,24 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     HIPCHK(hipEventCreate(&ev));
     h->evPool.push_back(ev);
   }
-  int nLaunch = 0;
+  int nLaunch = 0, fusedSteps = 0;
   if ((h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0) {
     // fused path: `chunk` env steps per launch, every wave runs its envs through the whole chunk and emits obs/LCD itself;
     // slots are re-binned by work class between chunks
-    for (int t = 0; t < T; t += h->rolloutChunk) {
-      int c = T - t < h->rolloutChunk ? T - t : h->rolloutChunk;
+    // Chunk length.  Joint-free scenes re-bin their slots between chunks (work classes drift: impacts, sleep) and keep 20.
+    // Jointed scenes are never re-binned, and every launch ends with all SIMDs waiting for the slowest wave, so longer
+    // launches average that tail out (Urchin-50k +8 %, LuxoBall-50k +17 % at one launch per 200-step rollout): as long as the
+    // previous rollout's time per env step allows, up to ~1.5 s per launch.  Results do not depend on the chunking.
+    int chunk = h->rolloutChunk;
+    if (!h->chunkFixed && h->rebinEvery == 0 && h->hostScene.nj > 0) {
+      chunk = 50;
+      if (h->estMsPerStep > 0.0f) {
+        float c = 1500.0f / h->estMsPerStep;
+        chunk = c < 20.0f ? 20 : (c > 200.0f ? 200 : (int)c);
+      }
+    }
+    for (int t = 0; t < T; t += chunk) {
+      int c = T - t < chunk ? T - t : chunk;
       const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
       if ((rc = launch_step(h, a, c, 0, 0, h->evPool[2 * nLaunch], h->evPool[2 * nLaunch + 1], (long long)h->N * nact,
                             dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr, dObs ? (float*)dObs + obsStep * t : nullptr)))
@@ -1045,6 +1062,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
       ++nLaunch;
       if (t + c < T && (rc = maybe_rebin(h, c))) return rc;
     }
+    fusedSteps = T;
   } else {
     for (int t = 0; t < T; ++t) {
       const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
@@ -1065,6 +1083,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     total += ms;
   }
   h->lastMs = total;
+  if (fusedSteps > 0) h->estMsPerStep = total / (float)fusedSteps;
   if ((rc = out_done(h, 1, lcd_out, lcdStep * T, dLcd))) return rc;
   if ((rc = out_done(h, 2, obs_out, obsStep * T * sizeof(float), dObs))) return rc;
   return fault_status(h);
