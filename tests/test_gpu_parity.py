@@ -254,3 +254,35 @@ def test_fused_rollout_ragged_batch_matches_oracle(name, n):
       assert (lcd[t, e] == o.render()).all() and np.abs(obs[t, e] - o.obs()).max() < 1e-6, (e, t)
   assert not h.faults().any()
   h.close()
+
+
+@pytest.mark.parametrize('name', ['Urchin', 'LuxoBall', 'Object2'])
+def test_rollout_results_do_not_depend_on_the_launch_chunking(name, monkeypatch):
+  """blcd_rollout sizes its fused launches itself (joint-free scenes: 20 env-steps + re-binning; jointed scenes: up to 200,
+  from the previous rollout's time per step).  Whatever the chunking, frames, observations and final state are the same."""
+  n, T = 192, 60
+  env, poses, sel = parity.make_batch(name, n, 5)
+  d = env.scene.desc
+  acts = np.random.RandomState(6).uniform(-1, 1, (T, n, max(1, d.n_act))).astype(np.float32)[:, :, :d.n_act]
+  outs = []
+  for chunk in (None, '7', '1'):
+    if chunk is None:
+      monkeypatch.delenv('BLCD_CHUNK', raising=False)
+    else:
+      monkeypatch.setenv('BLCD_CHUNK', chunk)
+    h = Handle(d, n, 0)
+    res = []
+    for rep in range(2):      # the second rollout of the adaptive handle uses the measured time per step
+      h.reset(None, poses, sel)
+      lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+      obs = np.zeros((T, n, d.n_obs), np.float32)
+      h.rollout(acts, T, lcd, obs)
+      res.append((lcd, obs, [x.copy() for x in h.debug_dump()]))
+    h.close()
+    outs.append(res)
+  ref = outs[0][0]
+  for res in outs:
+    for lcd, obs, dump in res:
+      assert (lcd == ref[0]).all() and (obs == ref[1]).all()
+      for a, b in zip(dump, ref[2]):
+        assert (a == b).all()
