@@ -140,7 +140,7 @@ struct Stats {
   long cycleAtSum = 0, cycleCount = 0;  // diagnostic: first velocity sweep after which the state is a fixed point (181 = never)
   bool trackSweeps = false;
   long nicHist[16] = {0};      // diagnostic (trackSweeps): contacts per solved island (15 = 15 or more), jointed islands only
-  std::vector<int> solveLog;   // diagnostic (trackSweeps): per island solve {fixedAt, cyclePeriod, cycleAt, nJoints}
+  std::vector<int> solveLog;   // diagnostic (trackSweeps): per island solve {fixedAt, cyclePeriod, cycleAt, nJoints, nContacts, nBodies}
   int lastSolveSweeps = 0;     // diagnostic: max over this world step's island solves of the sweeps an exact early exit needs (fixed point, or a cycle of period <= 4 seen within 24 sweeps; else all)
 };
 
@@ -1249,7 +1249,7 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
   if (stats.trackSweeps) { stats.periodHist[cyclePeriod == 0 ? 33 : cyclePeriod]++; if (cyclePeriod) { stats.cycleAtSum += cycleAt; stats.cycleCount++; } }
   if (stats.trackSweeps) stats.sweepHist[fixedAt < 0 ? 181 : fixedAt + 1]++;
   if (stats.trackSweeps) {
-    stats.solveLog.insert(stats.solveLog.end(), {fixedAt, cyclePeriod, cycleAt, (int)ijoints.size()});
+    stats.solveLog.insert(stats.solveLog.end(), {fixedAt, cyclePeriod, cycleAt, (int)ijoints.size(), (int)icontacts.size(), (int)ibodies.size()});
     if (!ijoints.empty()) stats.nicHist[icontacts.size() < 15 ? icontacts.size() : 15]++;
     int need = step.velocityIterations;
     if (fixedAt >= 0) need = fixedAt + 1;
