@@ -110,14 +110,14 @@ struct RContact {  // velocity + position constraint of one contact in island or
 //    velocity sweep by a handful of ds_read/ds_write (ISA of the (4,3,16) class), and frees 10 * NB VGPRs.
 // Pure data movement either way: the arithmetic is untouched.
 //  * CLDS = true (with LDS): the sweep-invariant part of every contact's velocity constraint (lever arms, effective masses,
-//    bias, normal, block matrices: 23 words per contact) is parked in a second LDS block [word][lane] with compile-time
+//    bias, normal, block matrices: 22 words per contact) is parked in a second LDS block [word][lane] with compile-time
 //    offsets, and only the accumulated impulses stay in registers.  The hot set of a 3-joint + 4-contact island is ~260
 //    words against 256 VGPRs, so without this ~400 v_accvgpr moves per sweep shuttle it through the AGPR half.
 template <int NB, int NJR, int NCR, bool LDS = false, bool CLDS = false>
 struct RegIsland {
   static constexpr int kBodyWords = 10;   // v.x v.y w | c.x c.y a | invMass invI lc.x lc.y
   static constexpr int kLdsWords = kBodyWords * NB * 64;
-  static constexpr int kCtWords = 23;     // per point {rA rB normalMass tangentMass velocityBias} x2 | normal | normalMass(3) | K(3) | friction
+  static constexpr int kCtWords = 22;     // per point {rA rB normalMass tangentMass velocityBias} x2 | normal | normalMass(3) | K(3)
   static constexpr int kCtLdsWords = kCtWords * NCR * 64;
   float* C;        // CLDS mode: this lane's column of the contact-constant block
   BodyVel vel[LDS ? 1 : NB];
@@ -254,7 +254,7 @@ struct RegIsland {
       q.nm.ey = V2(p[64 * 17], p[64 * 18]);     // inverse of a symmetric matrix: ex.y == ey.x bit for bit (b2Mat22::GetInverse)
       q.K.ex = V2(p[64 * 19], p[64 * 20]);
       q.K.ey = V2(p[64 * 20], p[64 * 21]);
-      q.friction = p[64 * 22];
+      q.friction = c_.friction;
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -292,7 +292,6 @@ struct RegIsland {
       p[64 * 19] = q.K.ex.x;
       p[64 * 20] = q.K.ex.y;
       p[64 * 21] = q.K.ey.y;
-      p[64 * 22] = q.friction;
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {

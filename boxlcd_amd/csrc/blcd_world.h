@@ -1431,8 +1431,10 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   static constexpr bool kUseReg = (NB > 1) && (NB <= BLCD_REG_MAXNB) && (NJ <= 4);   // NB = 7: re-enabled in round 2 (parity incl. a -ftrivial-auto-var-init=pattern build; UrchinBalls +26 %), see DESIGN.md
   static constexpr int kRegC = 4;
-  static constexpr bool kRegLds = BLCD_REG_LDS && NB >= 4;   // body rows of the staged island live in LDS (see RegIsland)
-  static constexpr bool kRegCtLds = kRegLds && BLCD_REG_CLDS && NB <= 5;   // + the contacts' sweep constants (LDS budget: 4 waves per CU)
+  static constexpr bool kRegLds = kUseReg && BLCD_REG_LDS && NB >= 4;   // body rows of the staged island live in LDS (see RegIsland)
+  static constexpr bool kRegCtLds = kRegLds && BLCD_REG_CLDS;   // + the contacts' sweep constants.  LDS budget = 40 KB per wave
+  // (four waves per CU): body rows 10 KB x NB/4 + 22 KB of contact constants; the frame-store staging rows of step_kernel
+  // (4.3 KB) live in the contact block, which is dead while a frame is written (ldsFrameRows)
   using RegI = RegIsland<NB, NJ, kRegC, kRegLds, kRegCtLds>;
   // this lane's column of the wave's staged-island LDS block (one block per kernel: the main solve and the TOI
   // mini-islands never overlap in time)
@@ -1444,13 +1446,18 @@ struct Env {
       return nullptr;
     }
   }
+  static __device__ __forceinline__ float* ctLdsBase() {
+    __shared__ float blk[kRegCtLds ? RegI::kCtLdsWords : 64 * 17];
+    return blk;
+  }
   __device__ __forceinline__ float* regContactLds() {
-    if constexpr (kRegCtLds) {
-      __shared__ float blk[RegI::kCtLdsWords];
-      return blk + threadIdx.x;
-    } else {
-      return nullptr;
-    }
+    if constexpr (kRegCtLds) return ctLdsBase() + threadIdx.x;
+    else return nullptr;
+  }
+  // 64 x 17 words for step_kernel's wave-coalesced 16x16 frame stores
+  static __device__ __forceinline__ uint32_t* ldsFrameRows() {
+    static_assert(!kRegCtLds || RegI::kCtLdsWords >= 64 * 17, "frame rows must fit the contact block");
+    return reinterpret_cast<uint32_t*>(ctLdsBase());
   }
   __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
     const int nb = S->nb;
