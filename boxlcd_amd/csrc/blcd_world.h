@@ -26,6 +26,9 @@
 #ifndef BLCD_REG_LDS
 #define BLCD_REG_LDS 1     // classes with >= 4 bodies keep the staged island's body rows in LDS instead of select chains
 #endif
+#ifndef BLCD_GEN_LDS
+#define BLCD_GEN_LDS 1     // largest class: the generic island's per-body arrays live in LDS
+#endif
 #ifndef BLCD_REG_CLDS
 #define BLCD_REG_CLDS 1    // ... and (<= 5 bodies) the contacts' sweep-invariant constants too
 #endif
@@ -216,6 +219,33 @@ struct ByteVec {
 // SH = shape set of the scene, known when the handle is created: 0 = anything, 1 = every dynamic body is a circle.
 // Circles-only scenes (Bounce, Bounce2) get kernels without the polygon routines (edge-polygon / polygon-polygon collide,
 // 2-point manifolds and the block solver, polygon TOI proxies, polygon raster): far fewer live registers.
+// Per-body working arrays of the generic island (positions / velocities of the island's bodies, indexed with run-time body
+// ids).  Small classes: plain per-thread arrays.  The largest class (17-20 bodies): columns of an LDS block [body][lane],
+// so that a run-time index is an LDS address (~100 cycles) instead of a scratch access behind 25 KB per lane of private
+// memory (the class's generic solver is bound by that latency).
+template <typename T, int N, bool LDS>
+struct BodyCol {
+  T a[N];
+  __device__ __forceinline__ T get(int i) const { return a[i]; }
+  __device__ __forceinline__ void set(int i, const T& v) { a[i] = v; }
+};
+typedef __attribute__((address_space(3))) float LdsFloat;
+template <int N>
+struct BodyCol<float, N, true> {
+  LdsFloat* p;   // this lane's element of row 0; rows are 64 lanes apart
+  __device__ __forceinline__ float get(int i) const { return p[i * 64]; }
+  __device__ __forceinline__ void set(int i, float v) const { p[i * 64] = v; }
+};
+template <int N>
+struct BodyCol<Vec2, N, true> {
+  LdsFloat* p;   // this lane's x of row 0; a row is 64 lanes x (x, y)
+  __device__ __forceinline__ Vec2 get(int i) const { return V2(p[i * 128], p[i * 128 + 1]); }
+  __device__ __forceinline__ void set(int i, const Vec2& v) const {
+    p[i * 128] = v.x;
+    p[i * 128 + 1] = v.y;
+  }
+};
+
 template <int NB, int NJ, int NP, int SH = 0>
 struct Env {
   static constexpr bool kCirc = SH == 1;
@@ -271,8 +301,9 @@ struct Env {
   unsigned long long prof[8];
   bool profOn;
   // --- island scratch ---
-  Vec2 pc[NB], pv[NB];
-  float pa[NB], pw[NB];
+  static constexpr bool kGenLds = BLCD_GEN_LDS && NB > 7;
+  BodyCol<Vec2, NB, kGenLds> pc, pv;
+  BodyCol<float, NB, kGenLds> pa, pw;
   VC vc[kMaxC];
   ByteVec<NP> ic;
   // short-cycle detector for the velocity sweeps (islands without joints only)
@@ -289,6 +320,14 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void load(const DevScene* scene, const float* __restrict__ st, int N, int e) {
     S = scene;
+    if constexpr (kGenLds) {   // 6 words x NB bodies x 64 lanes (30 KB for NB = 20)
+      __shared__ float blk[6 * NB * 64];
+      LdsFloat* base = (LdsFloat*)blk;
+      pc.p = base + 2 * threadIdx.x;
+      pv.p = base + 2 * NB * 64 + 2 * threadIdx.x;
+      pa.p = base + 4 * NB * 64 + threadIdx.x;
+      pw.p = base + 5 * NB * 64 + threadIdx.x;
+    }
     const int nb = S->nb, nj = S->nj, np = S->np;
     awakeMask = 0;
     deadQ = 15u;
@@ -735,23 +774,23 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   // island state accessors: dynamic bodies from pc/pa/pv/pw, walls constant
   // ------------------------------------------------------------------------------------------------
-  __device__ __forceinline__ Vec2 Pc(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pc[bi(p)]; }
-  __device__ __forceinline__ float Pa(int p) const { return p < 4 ? 0.0f : pa[bi(p)]; }
-  __device__ __forceinline__ Vec2 Pv(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pv[bi(p)]; }
-  __device__ __forceinline__ float Pw(int p) const { return p < 4 ? 0.0f : pw[bi(p)]; }
+  __device__ __forceinline__ Vec2 Pc(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pc.get(bi(p)); }
+  __device__ __forceinline__ float Pa(int p) const { return p < 4 ? 0.0f : pa.get(bi(p)); }
+  __device__ __forceinline__ Vec2 Pv(int p) const { return p < 4 ? V2(0.0f, 0.0f) : pv.get(bi(p)); }
+  __device__ __forceinline__ float Pw(int p) const { return p < 4 ? 0.0f : pw.get(bi(p)); }
   __device__ __forceinline__ float mOf(int p) const { return p < 4 ? 0.0f : invMass[bi(p)]; }
   __device__ __forceinline__ float iOf(int p) const { return p < 4 ? 0.0f : invI[bi(p)]; }
   __device__ __forceinline__ Vec2 lcOf(int p) const { return p < 4 ? V2(0.0f, 0.0f) : lc[bi(p)]; }
   __device__ __forceinline__ void setVel(int p, Vec2 vv, float ww) {
     if (p >= 4) {
-      pv[bi(p)] = vv;
-      pw[bi(p)] = ww;
+      pv.set(bi(p), vv);
+      pw.set(bi(p), ww);
     }
   }
   __device__ __forceinline__ void setPos(int p, Vec2 cc, float aa) {
     if (p >= 4) {
-      pc[bi(p)] = cc;
-      pa[bi(p)] = aa;
+      pc.set(bi(p), cc);
+      pa.set(bi(p), aa);
     }
   }
 
@@ -1096,12 +1135,12 @@ struct Env {
   __device__ __forceinline__ void jointInit(int j, bool warmStarting, float dtRatio) {
     const DevJoint& J = S->joints[j];
     int A = J.bodyA, B = J.bodyB;
-    float aA = pa[A];
-    Vec2 vA = pv[A];
-    float wA = pw[A];
-    float aB = pa[B];
-    Vec2 vB = pv[B];
-    float wB = pw[B];
+    float aA = pa.get(A);
+    Vec2 vA = pv.get(A);
+    float wA = pw.get(A);
+    float aB = pa.get(B);
+    Vec2 vB = pv.get(B);
+    float wB = pw.get(B);
     Rot qA = MakeRot(aA), qB = MakeRot(aB);
     jrA[j] = Mul(qA, J.anchorA - lc[A]);
     jrB[j] = Mul(qB, J.anchorB - lc[B]);
@@ -1152,20 +1191,20 @@ struct Env {
       jimp[j] = Vec3{0.0f, 0.0f, 0.0f};
       jmotor[j] = 0.0f;
     }
-    pv[A] = vA;
-    pw[A] = wA;
-    pv[B] = vB;
-    pw[B] = wB;
+    pv.set(A, vA);
+    pw.set(A, wA);
+    pv.set(B, vB);
+    pw.set(B, wB);
   }
 
   __device__ __forceinline__ bool jointSolveVelocity(int j, float dt) {
     bool changed = false;
     const DevJoint& J = S->joints[j];
     int A = J.bodyA, B = J.bodyB;
-    Vec2 vA = pv[A];
-    float wA = pw[A];
-    Vec2 vB = pv[B];
-    float wB = pw[B];
+    Vec2 vA = pv.get(A);
+    float wA = pw.get(A);
+    Vec2 vB = pv.get(B);
+    float wB = pw.get(B);
     float mA = invMass[A], mB = invMass[B];
     float iA = invI[A], iB = invI[B];
     Vec2 rA = jrA[j], rB = jrB[j];
@@ -1239,20 +1278,20 @@ struct Env {
       vB += mB * impulse;
       wB += iB * Cross(rB, impulse);
     }
-    pv[A] = vA;
-    pw[A] = wA;
-    pv[B] = vB;
-    pw[B] = wB;
+    pv.set(A, vA);
+    pw.set(A, wA);
+    pv.set(B, vB);
+    pw.set(B, wB);
     return changed;
   }
 
   __device__ __forceinline__ bool jointSolvePosition(int j) {
     const DevJoint& J = S->joints[j];
     int A = J.bodyA, B = J.bodyB;
-    Vec2 cA = pc[A];
-    float aA = pa[A];
-    Vec2 cB = pc[B];
-    float aB = pa[B];
+    Vec2 cA = pc.get(A);
+    float aA = pa.get(A);
+    Vec2 cB = pc.get(B);
+    float aB = pa.get(B);
     float mA = invMass[A], mB = invMass[B];
     float iA = invI[A], iB = invI[B];
     float angularError = 0.0f;
@@ -1297,10 +1336,10 @@ struct Env {
       cB += mB * impulse;
       aB += iB * Cross(rB, impulse);
     }
-    pc[A] = cA;
-    pa[A] = aA;
-    pc[B] = cB;
-    pa[B] = aB;
+    pc.set(A, cA);
+    pa.set(A, aA);
+    pc.set(B, cB);
+    pa.set(B, aB);
     return positionError <= kLinearSlop && angularError <= kAngularSlop;
   }
 
@@ -1324,9 +1363,10 @@ struct Env {
 #pragma unroll
     for (int i = 0; i < kCycNB; ++i) {
       if ((ibmask >> i) & 1) {
-        dst.v[3 * i] = pv[i].x;
-        dst.v[3 * i + 1] = pv[i].y;
-        dst.v[3 * i + 2] = pw[i];
+        const Vec2 pvi_ = pv.get(i);
+        dst.v[3 * i] = pvi_.x;
+        dst.v[3 * i + 1] = pvi_.y;
+        dst.v[3 * i + 2] = pw.get(i);
       }
     }
 #pragma unroll
@@ -1345,9 +1385,8 @@ struct Env {
 #pragma unroll
     for (int i = 0; i < kCycNB; ++i) {
       if ((ibmask >> i) & 1) {
-        pv[i].x = src.v[3 * i];
-        pv[i].y = src.v[3 * i + 1];
-        pw[i] = src.v[3 * i + 2];
+        pv.set(i, V2(src.v[3 * i], src.v[3 * i + 1]));
+        pw.set(i, src.v[3 * i + 2]);
       }
     }
 #pragma unroll
@@ -1403,10 +1442,10 @@ struct Env {
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
       if (!((ibmask >> i) & 1)) continue;
-      Vec2 c_ = pc[i];
-      float a_ = pa[i];
-      Vec2 v_ = pv[i];
-      float w_ = pw[i];
+      Vec2 c_ = pc.get(i);
+      float a_ = pa.get(i);
+      Vec2 v_ = pv.get(i);
+      float w_ = pw.get(i);
       Vec2 translation = h * v_;
       if (Dot(translation, translation) > kMaxTranslationSquared) {
         float ratio = kMaxTranslation / Length(translation);
@@ -1419,10 +1458,10 @@ struct Env {
       }
       c_ += h * v_;
       a_ += h * w_;
-      pc[i] = c_;
-      pa[i] = a_;
-      pv[i] = v_;
-      pw[i] = w_;
+      pc.set(i, c_);
+      pa.set(i, a_);
+      pv.set(i, v_);
+      pw.set(i, w_);
     }
   }
 
@@ -1777,10 +1816,10 @@ struct Env {
       w_ += h * invI[i] * 0.0f;
       v_ *= Clamp(1.0f - h * S->bodies[i].linearDamping, 0.0f, 1.0f);      // Box2D 2.3.0 (first-order; >= 2.3.1 is Pade)
       w_ *= Clamp(1.0f - h * S->bodies[i].angularDamping, 0.0f, 1.0f);
-      pc[i] = c[i];
-      pa[i] = a[i];
-      pv[i] = v_;
-      pw[i] = w_;
+      pc.set(i, c[i]);
+      pa.set(i, a[i]);
+      pv.set(i, v_);
+      pw.set(i, w_);
     }
     csInit(nic, true, dtRatio);
     csInitVelocityConstraints(nic);
@@ -1807,10 +1846,10 @@ struct Env {
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
       if (!((ibmask >> i) & 1)) continue;
-      c[i] = pc[i];
-      a[i] = pa[i];
-      v[i] = pv[i];
-      w[i] = pw[i];
+      c[i] = pc.get(i);
+      a[i] = pa.get(i);
+      v[i] = pv.get(i);
+      w[i] = pw.get(i);
       syncTransform(i);
     }
     float minSleepTime = kMaxFloat;
@@ -2254,26 +2293,26 @@ struct Env {
         }
       }
       if (!toiDone) {
-      pc[b] = c[b];
-      pa[b] = a[b];
-      pv[b] = v[b];
-      pw[b] = w[b];
+      pc.set(b, c[b]);
+      pa.set(b, a[b]);
+      pv.set(b, v[b]);
+      pw.set(b, w[b]);
       csInit(nic, false, 1.0f);
       for (int it = 0; it < 20; ++it) {
         float minSeparation = csSolvePosition(nic, true, pB);
         if (minSeparation >= -1.5f * kLinearSlop) break;
       }
-      c0[b] = pc[b];
-      a0[b] = pa[b];
+      c0[b] = pc.get(b);
+      a0[b] = pa.get(b);
       QT(4);
       csInitVelocityConstraints(nic);
       velocitySweeps(1u << b, nic, 0, h);
       QT(5);
       integratePositions(1u << b, h);
-      c[b] = pc[b];
-      a[b] = pa[b];
-      v[b] = pv[b];
-      w[b] = pw[b];
+      c[b] = pc.get(b);
+      a[b] = pa.get(b);
+      v[b] = pv.get(b);
+      w[b] = pw.get(b);
       syncTransform(b);
       }
       // reset island flags, synchronize the broad phase, invalidate the body's contact TOIs
