@@ -1471,7 +1471,7 @@ struct Env {
   static constexpr bool kUseReg = (NB > 1) && (NB <= BLCD_REG_MAXNB) && (NJ <= 4);   // NB = 7: re-enabled in round 2 (parity incl. a -ftrivial-auto-var-init=pattern build; UrchinBalls +26 %), see DESIGN.md
   static constexpr int kRegC = 4;
   static constexpr bool kRegLds = kUseReg && BLCD_REG_LDS && NB >= 4;   // body rows of the staged island live in LDS (see RegIsland)
-  static constexpr bool kRegCtLds = kRegLds && BLCD_REG_CLDS;   // + the contacts' sweep constants.  LDS budget = 40 KB per wave
+  static constexpr bool kRegCtLds = kUseReg && NB >= 4 && BLCD_REG_CLDS;   // + the contacts' sweep constants.  LDS budget = 40 KB per wave
   // (four waves per CU): body rows 10 KB x NB/4 + 22 KB of contact constants; the frame-store staging rows of step_kernel
   // (4.3 KB) live in the contact block, which is dead while a frame is written (ldsFrameRows)
   using RegI = RegIsland<NB, NJ, kRegC, kRegLds, kRegCtLds>;
