@@ -91,6 +91,26 @@ static inline void sincosf_poly(double x, double x2, const SinCosTab* p, int n, 
 }
 
 
+// The same routine as glibc >= 2.28 selects through ifunc on x86-64 CPUs with FMA (sysdeps/x86_64/fpu/multiarch: the C
+// file compiled with -mfma -mavx2, GCC contracting every a + b * c): variant 3 of the sincos switch.
+static inline void sincosf_poly_fma(double x, double x2, const SinCosTab* p, int n, float* sinp, float* cosp) {
+  double x3, x4, x5, x6, s, c, c1, c2, s1;
+  x4 = x2 * x2;
+  x3 = x2 * x;
+  c2 = std::fma(x2, p->c4, p->c3);
+  s1 = std::fma(x2, p->s3, p->s2);
+  float* tmp = (n & 1 ? cosp : sinp);
+  cosp = (n & 1 ? sinp : cosp);
+  sinp = tmp;
+  c1 = std::fma(x2, p->c1, p->c0);
+  x5 = x3 * x2;
+  x6 = x4 * x2;
+  s = std::fma(x3, p->s1, x);
+  c = std::fma(x4, p->c2, c1);
+  *sinp = (float)std::fma(x5, s1, s);
+  *cosp = (float)std::fma(x6, c2, c);
+}
+
 // ---------------------------------------------------------------------------------------------
 // sinf / cosf of glibc <= 2.27 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h of 2.26/2.27 = the C form of the
 // x86_64 assembly used since 2.16): double-precision Chebyshev polynomials after a pi/2 table reduction.  This is the
@@ -188,7 +208,7 @@ static inline float b2o_cosf_g227(float x) {
 // Variant switches.  The DEFAULTS are the set that reproduces the reference's recordings from the recorder's own inputs
 // (tests/test_oracle_replay.py, DESIGN.md "replay table"): pybox2d 2.3.10 bundles Box2D 2.3.0, run on a glibc <= 2.27 libm.
 // The alternatives are kept so that the table in DESIGN.md can be regenerated (tools/replay_gifs.py --table).
-//   0 sincos      2 = glibc<=2.27 (default)  0 = glibc>=2.28   1 = (float)sin((double)x)
+//   0 sincos      2 = glibc<=2.27 (default)  0 = glibc>=2.28   3 = glibc>=2.28 as built for FMA CPUs   1 = (float)sin((double)x)
 //   1 damping     1 = Box2D 2.3.0 `v *= clamp(1 - h*c, 0, 1)` (default)   0 = >=2.3.1 Pade `v *= 1/(1 + h*c)`
 //   2 advance     1 = Box2D 2.3.0 `c0 = (1-beta)*c0 + beta*c` (default)   0 = >=2.3.1 `c0 += beta*(c - c0)`
 //   3 polygons    1 = Box2D 2.3.0 b2FindMaxSeparation hill climb + 0.98/0.001 face rule (default)   0 = >=2.3.1 brute force + k_tol
@@ -200,6 +220,11 @@ static inline int b2o_variant(int k) { return g_variant[k]; }
 static inline void b2o_sincosf(float y, float* sinp, float* cosp) {
   if (b2o_variant(0) == 1) { *sinp = (float)sin((double)y); *cosp = (float)cos((double)y); return; }
   if (b2o_variant(0) == 2) { *sinp = b2o_sinf_g227(y); *cosp = b2o_cosf_g227(y); return; }
+  const bool fmaPoly = b2o_variant(0) == 3;
+  auto poly = [&](double px, double px2, const SinCosTab* pp, int pn, float* ps, float* pc) {
+    if (fmaPoly) sincosf_poly_fma(px, px2, pp, pn, ps, pc);
+    else sincosf_poly(px, px2, pp, pn, ps, pc);
+  };
   double x = y;
   double s;
   int n;
@@ -211,14 +236,14 @@ static inline void b2o_sincosf(float y, float* sinp, float* cosp) {
       *cosp = 1.0f;
       return;
     }
-    sincosf_poly(x, x2, p, 0, sinp, cosp);
+    poly(x, x2, p, 0, sinp, cosp);
   } else if (abstop12(y) < abstop12(120.0f)) {
     double r = x * p->hpi_inv;
     n = ((int32_t)r + 0x800000) >> 24;
-    x = x - n * p->hpi;
+    x = fmaPoly ? std::fma(-(double)n, p->hpi, x) : x - n * p->hpi;
     s = p->sign[n & 3];
     if (n & 2) p = &kSinCosTab[1];
-    sincosf_poly(x * s, x * x, p, n, sinp, cosp);
+    poly(x * s, x * x, p, n, sinp, cosp);
   } else if (abstop12(y) < abstop12(INFINITY)) {
     uint32_t xi = asuint(y);
     int sign = xi >> 31;
@@ -239,7 +264,7 @@ static inline void b2o_sincosf(float y, float* sinp, float* cosp) {
     x = x * 0x1.921FB54442D18p-62;
     s = p->sign[(n + sign) & 3];
     if ((n + sign) & 2) p = &kSinCosTab[1];
-    sincosf_poly(x * s, x * x, p, n, sinp, cosp);
+    poly(x * s, x * x, p, n, sinp, cosp);
   } else {
     *sinp = *cosp = y - y;
   }
