@@ -1499,6 +1499,9 @@ struct Env {
     return reinterpret_cast<uint32_t*>(ctLdsBase());
   }
   __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
+#ifdef BLCD_PROF_SOLVE
+    const unsigned long long psE_ = __builtin_amdgcn_s_memtime();
+#endif
     const int nb = S->nb;
     Vec2 gravity = S->gravity;
     RegI R;
@@ -1592,6 +1595,9 @@ struct Env {
     }
 #ifdef BLCD_PROF_SOLVE
     unsigned long long ps0_ = __builtin_amdgcn_s_memtime();
+#ifndef BLCD_PROF_SOLVE2
+    prof[3] += ps0_ - psE_;     // staging + constraint initialisation + warm start
+#endif
 #endif
     int sweeps = R.velocitySweeps(S->velIters, h);
 #ifdef BLCD_PROF_SOLVE
@@ -1993,11 +1999,17 @@ struct Env {
         islandSolve(ibmask, nic, nij, h, dtRatio);
       }
     }
+#ifdef BLCD_PROF_SOLVE2
+    const unsigned long long psS_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int i = NB - 1; i >= 0; --i) {
       if (i >= nb) continue;
       if ((bodyIsland >> i) & 1) synchronizeFixtures(i);
     }
     findNewContacts(false);
+#ifdef BLCD_PROF_SOLVE2
+    prof[3] += __builtin_amdgcn_s_memtime() - psS_;   // SynchronizeFixtures + FindNewContacts
+#endif
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -2324,7 +2336,9 @@ struct Env {
       findNewContacts(false);
       QT(6);
 #ifndef BLCD_PROF_TOI2
+#ifndef BLCD_PROF_SOLVE2
       if (profOn) prof[3] += __builtin_amdgcn_s_memtime() - e0_;
+#endif
 #endif
       PT(5);
     }
