@@ -1,13 +1,15 @@
-// blcd_island_reg.h — register-resident b2Island::Solve for small islands (<= NJR joints, <= NCR contacts).
+// blcd_island_reg.h — staged b2Island::Solve for small islands (<= NJR joints, <= NCR contacts): constraints in registers,
+// body rows and the contacts' sweep constants in registers (2-3 bodies) or in the wave's LDS (>= 4 bodies).
 //
 // The 540 Gauss-Seidel velocity sweeps per env step are the hot loop of the path (b2Island::Solve,
 // b2ContactSolver::SolveVelocityConstraints, b2RevoluteJoint::SolveVelocityConstraints; reference call site
 // boxLCD/world_env.py:448-450).  In the generic Env the constraint arrays are indexed with run-time values (island order is
 // dynamic), which keeps them in scratch: measured 27 k cycles per sweep for an Urchin (3 joints + ~3 contacts).  Here the
 // island's working set is staged once per world step into statically indexed structures, in island (DFS) order, so that
-// the sweeps run entirely out of VGPRs:
+// the sweeps run out of VGPRs and LDS:
 //   * constraints k = 0..n-1 are unrolled (static index), each remembers its two body ids;
-//   * body velocities/positions are small arrays read/written through compare-select chains on the body id.
+//   * body velocities/positions/masses are rows addressed by body id: compare-select chains over small register arrays for
+//     2-3 bodies, an LDS block [word][lane] for more (see RegIsland below; 17 k -> 11 k cycles per sweep on the final build).
 // Arithmetic and operation order are exactly those of the generic path (and of Box2D); the parity tests compare both
 // against the CPU oracle.  Islands that do not fit fall back to the generic path.
 #pragma once
