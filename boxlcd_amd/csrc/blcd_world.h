@@ -1469,9 +1469,14 @@ struct Env {
   // register-resident island solve (blcd_island_reg.h) for multi-body scenes: islands with <= kRegC contacts
   // ------------------------------------------------------------------------------------------------
   static constexpr bool kUseReg = (NB > 1) && (NB <= BLCD_REG_MAXNB) && (NJ <= 4);   // NB = 7: re-enabled in round 2 (parity incl. a -ftrivial-auto-var-init=pattern build; UrchinBalls +26 %), see DESIGN.md
-  static constexpr int kRegC = 4;
+#ifndef BLCD_REGC7
+#define BLCD_REGC7 6
+#endif
+  // contacts per staged island.  Robot + one object: 5 or more contacts in 0.03 % of solves; robot + three objects (7-body
+  // class): 1.0-1.6 % (b2o_nic_hist), and ONE such lane sends the whole wave through the generic scratch-resident solver
+  static constexpr int kRegC = NB >= 7 ? BLCD_REGC7 : 4;
   static constexpr bool kRegLds = kUseReg && BLCD_REG_LDS && NB >= 4;   // body rows of the staged island live in LDS (see RegIsland)
-  static constexpr bool kRegCtLds = kUseReg && NB >= 4 && BLCD_REG_CLDS;   // + the contacts' sweep constants.  LDS budget = 40 KB per wave
+  static constexpr bool kRegCtLds = kUseReg && NB >= 4 && BLCD_REG_CLDS && (10 * NB + 22 * kRegC) * 256 <= 40960;   // + the contacts' sweep constants.  LDS budget = 40 KB per wave
   // (four waves per CU): body rows 10 KB x NB/4 + 22 KB of contact constants; the frame-store staging rows of step_kernel
   // (4.3 KB) live in the contact block, which is dead while a frame is written (ldsFrameRows)
   using RegI = RegIsland<NB, NJ, kRegC, kRegLds, kRegCtLds>;
