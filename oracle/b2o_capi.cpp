@@ -355,6 +355,7 @@ void b2o_track_sweeps(b2o_env* e, int32_t on) { e->world.stats.trackSweeps = on 
 int32_t b2o_solve_log(b2o_env* e, int32_t* out, int32_t cap) {   // copies and clears; returns the number of ints
   auto& v = e->world.stats.solveLog; int n = (int)v.size() < cap ? (int)v.size() : cap; for (int i = 0; i < n; ++i) out[i] = v[i]; v.clear(); return n; }
 void b2o_nic_hist(b2o_env* e, int64_t* out16) { for (int i = 0; i < 16; ++i) out16[i] = e->world.stats.nicHist[i]; }
+void b2o_nic_hist_free(b2o_env* e, int64_t* out16) { for (int i = 0; i < 16; ++i) out16[i] = e->world.stats.nicHistFree[i]; }
 int32_t b2o_last_solve_sweeps(b2o_env* e) { int v = e->world.stats.lastSolveSweeps; e->world.stats.lastSolveSweeps = 0; return v; }   // read-and-reset
 void b2o_sweep_hist(b2o_env* e, int64_t* out182) {
   for (int i = 0; i < 182; ++i) out182[i] = e->world.stats.sweepHist[i];

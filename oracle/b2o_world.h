@@ -139,6 +139,7 @@ struct Stats {
   long periodHist[34] = {0};   // diagnostic: period (1..32) of the sweep-state cycle when one is detected, [33] = none, [0] unused
   long cycleAtSum = 0, cycleCount = 0;  // diagnostic: first velocity sweep after which the state is a fixed point (181 = never)
   bool trackSweeps = false;
+  long nicHistFree[16] = {0};  // the same for joint-free islands
   long nicHist[16] = {0};      // diagnostic (trackSweeps): contacts per solved island (15 = 15 or more), jointed islands only
   std::vector<int> solveLog;   // diagnostic (trackSweeps): per island solve {fixedAt, cyclePeriod, cycleAt, nJoints, nContacts, nBodies}
   int lastSolveSweeps = 0;     // diagnostic: max over this world step's island solves of the sweeps an exact early exit needs (fixed point, or a cycle of period <= 4 seen within 24 sweeps; else all)
@@ -1251,6 +1252,7 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
   if (stats.trackSweeps) {
     stats.solveLog.insert(stats.solveLog.end(), {fixedAt, cyclePeriod, cycleAt, (int)ijoints.size(), (int)icontacts.size(), (int)ibodies.size()});
     if (!ijoints.empty()) stats.nicHist[icontacts.size() < 15 ? icontacts.size() : 15]++;
+    else stats.nicHistFree[icontacts.size() < 15 ? icontacts.size() : 15]++;
     int need = step.velocityIterations;
     if (fixedAt >= 0) need = fixedAt + 1;
     else if (ijoints.empty() && cyclePeriod >= 1 && cyclePeriod <= 4 && cycleAt < 24) need = cycleAt + 1;
