@@ -891,10 +891,7 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   hipLaunchKernelGGL(iota_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, n_envs);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
-  // re-binning pays when environments sleep / fly freely (no joints keep them awake); BLCD_REBIN overrides (0 = off)
-  h->rebinEvery = h->hostScene.nj == 0 ? 1 : 0;
   if (const char* ev = getenv("BLCD_BINMODE")) h->binMode = atoi(ev);
-  if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
   if (getenv("BLCD_WAVETIMES")) HIPCHK(hipMalloc((void**)&h->waveTimes, (size_t)n_envs * 9 * sizeof(unsigned long long)));
   if (const char* ev = getenv("BLCD_CHUNK")) {
     h->rolloutChunk = atoi(ev);
@@ -912,7 +909,14 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
       int l = (n_envs + simds - 1) / simds;
       h->lanes = l < 16 ? 16 : (l > 64 ? 64 : l);   // below ~16 lanes the scratch footprint per useful lane costs more than the narrower union saves (Urchin-4096: 76 / 66 / 97 ms at 64 / 16 / 4 lanes)
     }
+    // Re-binning by work class.  It pays when environments sleep / fly freely (no joints keep them awake) AND the batch
+    // oversubscribes the SIMDs, so that total wave time is what counts: Bounce-100k 1.66e9 with, 1.09e9 without.  With at most
+    // one wave per SIMD the launch lasts as long as its slowest wave, a wave's cost is convex in its number of heavy lanes, and
+    // concentrating them makes that wave slower: Bounce-50k +9 %, Dropbox-50k +12 %, Object2-50k +22 %, Object3-50k +30 %
+    // WITHOUT re-binning (and then the launches can be long, see blcd_rollout).  BLCD_REBIN overrides (0 = off).
+    h->rebinEvery = (h->hostScene.nj == 0 && simds > 0 && (long long)n_envs > 64LL * simds) ? 1 : 0;
   }
+  if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
   if (const char* ev = getenv("BLCD_LANES")) {
     int l = atoi(ev);
     if (l >= 1 && l <= 64) h->lanes = l;
@@ -1041,12 +1045,12 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
   if ((h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0) {
     // fused path: `chunk` env steps per launch, every wave runs its envs through the whole chunk and emits obs/LCD itself;
     // slots are re-binned by work class between chunks
-    // Chunk length.  Joint-free scenes re-bin their slots between chunks (work classes drift: impacts, sleep) and keep 20.
-    // Jointed scenes are never re-binned, and every launch ends with all SIMDs waiting for the slowest wave, so longer
-    // launches average that tail out (Urchin-50k +8 %, LuxoBall-50k +17 % at one launch per 200-step rollout): as long as the
+    // Chunk length.  Batches that are re-binned between chunks (joint-free scenes that oversubscribe the SIMDs: work classes
+    // drift with impacts and sleep) keep 20.  The others are never re-binned, and every launch ends with all SIMDs waiting for
+    // the slowest wave, so longer launches average that tail out (Urchin-50k +8 %, LuxoBall-50k +17 % at one launch per 200-step rollout): as long as the
     // previous rollout's time per env step allows, up to ~1.5 s per launch.  Results do not depend on the chunking.
     int chunk = h->rolloutChunk;
-    if (!h->chunkFixed && h->rebinEvery == 0 && h->hostScene.nj > 0) {
+    if (!h->chunkFixed && h->rebinEvery == 0) {
       chunk = 50;
       if (h->estMsPerStep > 0.0f) {
         float c = 1500.0f / h->estMsPerStep;

@@ -128,9 +128,9 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps);
 /* Fused rollout, replaces the inner loop of research/data.py:56-61 (`for j in range(ep_len): venv.step(act)`):
  * T env-steps with per-step actions [T][n_envs][n_act]; per-step outputs (any may be NULL):
  * lcd_out uint8 [T][n_envs][lcd_h][lcd_w], obs_out float32 [T][n_envs][n_obs].  All host|device.
- * The library cuts the T steps into fused launches itself (joint-free scenes: 20 env-steps with slot re-binning in between;
- * jointed scenes: up to 200, sized from the previous rollout's time per step; BLCD_CHUNK=<n> pins it) - results do not
- * depend on the cut. */
+ * The library cuts the T steps into fused launches itself (joint-free scenes in batches larger than 64 environments per
+ * SIMD: 20 env-steps with slot re-binning in between; everything else: up to 200, sized from the previous rollout's time
+ * per step; BLCD_CHUNK=<n> pins it) - results do not depend on the cut. */
 int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out);
 
 /* Replaces WorldEnv._get_obs() (world_env.py:387-429) incl. lcd_render() (:460-512).
