@@ -166,6 +166,12 @@ def main():
            '--master-port', os.environ.get('MASTER_PORT', '29533'), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd))
 
+  # stdout carries exactly ONE line, the JSON: libraries that chat on fd 1 (RCCL's start-up banner, gloo's "[Gloo] Rank ..."
+  # lines) are sent to stderr for the whole run, and rank 0 writes the result to the saved descriptor at the end
+  sys.stdout.flush()
+  json_fd = os.dup(1)
+  os.dup2(2, 1)
+
   import numpy as np
   import torch
   from boxlcd_amd import dist as bdist
@@ -239,7 +245,7 @@ def main():
       torch.cuda.empty_cache()
     out['configs'] = cfgs
   if rank == 0:
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
   if world > 1:
     torch.distributed.destroy_process_group()
 
