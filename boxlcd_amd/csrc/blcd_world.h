@@ -1473,7 +1473,7 @@ struct Env {
 #define BLCD_REGC7 6
 #endif
   // contacts per staged island.  Robot + one object: 5 or more contacts in 0.03 % of solves; robot + three objects (7-body
-  // class): 1.0-1.6 % (b2o_nic_hist), and ONE such lane sends the whole wave through the generic scratch-resident solver
+  // class): 1.0-1.6 % (measured on the CPU side), and ONE such lane sends the whole wave through the generic scratch-resident solver
   static constexpr int kRegC = (NB >= 7 || NB == 3) ? BLCD_REGC7 : 4;   // three free objects: 0.5 % of their islands hold 5-6 contacts
   static constexpr bool kRegLds = kUseReg && BLCD_REG_LDS && NB >= 4;   // body rows of the staged island live in LDS (see RegIsland)
   static constexpr bool kRegCtLds = kUseReg && NB >= 4 && BLCD_REG_CLDS && (10 * NB + 22 * kRegC) * 256 <= 40960;   // + the contacts' sweep constants.  LDS budget = 40 KB per wave
