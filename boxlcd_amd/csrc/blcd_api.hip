@@ -841,6 +841,10 @@ static std::mutex g_streamMutex;
 static std::vector<std::pair<int, hipStream_t>> g_deviceStream;
 static int acquire_stream(int device, hipStream_t* out) {
   std::lock_guard<std::mutex> lock(g_streamMutex);
+  if (getenv("BLCD_PRIVATE_STREAM")) {   // experiments only (cohorts on separate streams); see the note above about queues
+    HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return BLCD_OK;
+  }
   for (auto& e : g_deviceStream)
     if (e.first == device) {
       *out = e.second;
