@@ -124,7 +124,10 @@ class Workload:
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': None, 'kernel': 'step_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
             'env_steps_per_env_per_launch': steps_per_launch, 'alg_bytes_per_env_step': bpe,
-            'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'}
+            'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'
+                    + ('; this batch is stepped as two cohorts on two streams: a "launch" here is one chunk of the WHOLE batch (two '
+                       'concurrent step_kernel launches), avg_launch_ms = the overlapped sequence (re-bin kernels included) / chunks'
+                       if self.d.n_joints == 0 and self.N > 65536 and os.environ.get('BLCD_COHORTS', '2') != '1' else '')}
 
   def close(self):
     self.h.close()
@@ -207,8 +210,10 @@ def main():
       try:
         prof = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
         k = [x for x in prof if 'step_kernel' in x][0]
-        roof['traffic'] = (prof[k]['FETCH_SIZE']['mean'] + prof[k]['WRITE_SIZE']['mean']) * 1024.0
-        roof['traffic_source'] = f'{TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (KB -> B) per step_kernel launch of this same command; profile-derived, not measured in this run'
+        per_chunk = 1 if os.environ.get('BLCD_COHORTS', '2') == '1' else 2     # two cohort kernels make one chunk of the batch
+        roof['traffic'] = (prof[k]['FETCH_SIZE']['mean'] + prof[k]['WRITE_SIZE']['mean']) * 1024.0 * per_chunk
+        roof['traffic_source'] = (f'{TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (KB -> B) per step_kernel dispatch of this same '
+                                  f'command x {per_chunk} dispatches per chunk of the batch; profile-derived, not measured in this run')
       except Exception:
         roof['traffic'] = None
     out = {

@@ -269,13 +269,15 @@ __device__ inline int work_class(const DevScene* __restrict__ S, const float* __
   return kBins - 1 - (c < 8 ? c : 7);
 }
 
+// The three re-bin kernels sort ONE slot range (a cohort, or all slots): st / keys / eid point at the range's first slot, N stays
+// the stride between state fields, n is the number of slots in the range and lo its first slot (slotOf holds absolute slots).
 __global__ __launch_bounds__(kRebinBlock) void rebin_hist_kernel(const DevScene* __restrict__ S, const float* __restrict__ st,
-                                                                 int N, uint8_t* __restrict__ keys, int* __restrict__ counts, int mode) {
+                                                                 int N, int n, uint8_t* __restrict__ keys, int* __restrict__ counts, int mode) {
   __shared__ int h[kBins];
   if (threadIdx.x < kBins) h[threadIdx.x] = 0;
   __syncthreads();
   int slot = blockIdx.x * kRebinBlock + threadIdx.x;
-  if (slot < N) {
+  if (slot < n) {
     int k = work_class(S, st, N, slot, mode);
     keys[slot] = (uint8_t)k;
     atomicAdd(&h[k], 1);
@@ -312,14 +314,14 @@ __global__ void rebin_scan_kernel(const int* __restrict__ counts, int* __restric
 }
 
 // stable scatter: new slot = offset[bin][block] + rank of this slot among same-bin slots of the block (in slot order)
-__global__ __launch_bounds__(kRebinBlock) void rebin_move_kernel(const float* __restrict__ st, float* __restrict__ st2, int N,
+__global__ __launch_bounds__(kRebinBlock) void rebin_move_kernel(const float* __restrict__ st, float* __restrict__ st2, int N, int n, int lo,
                                                                  int words, const uint8_t* __restrict__ keys,
                                                                  const int* __restrict__ offsets, const int* __restrict__ eid,
                                                                  int* __restrict__ eid2, int* __restrict__ slotOf) {
   __shared__ int waveCount[kRebinBlock / 64][kBins];
   int slot = blockIdx.x * kRebinBlock + threadIdx.x;
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int key = slot < N ? (int)keys[slot] : -1;
+  int key = slot < n ? (int)keys[slot] : -1;
   int rankInWave = 0;
   for (int b = 0; b < kBins; ++b) {
     unsigned long long m = __ballot(key == b);
@@ -327,14 +329,14 @@ __global__ __launch_bounds__(kRebinBlock) void rebin_move_kernel(const float* __
     if (lane == 0) waveCount[wv][b] = __popcll(m);
   }
   __syncthreads();
-  if (slot >= N) return;
+  if (slot >= n) return;
   int base = offsets[key * gridDim.x + blockIdx.x];
   for (int w2 = 0; w2 < wv; ++w2) base += waveCount[w2][key];
   int dst = base + rankInWave;
   for (int f = 0; f < words; ++f) st2[(size_t)f * N + dst] = st[(size_t)f * N + slot];
   int e = eid[slot];
   eid2[dst] = e;
-  slotOf[e] = dst;
+  slotOf[e] = lo + dst;
 }
 
 __global__ void invert_kernel(const int* __restrict__ eid, int* __restrict__ slotOf, int n) {
@@ -559,6 +561,13 @@ struct blcd_handle_s {
   float estMsPerStep = 0.0f;  // step-kernel time per env step of the last fused rollout (sizes the chunks of jointed scenes)
   unsigned long long* waveTimes = nullptr;  // per-wave duration of the last step launch (diagnostic, BLCD_WAVETIMES=1)
   int stepsSinceRebin = 0;
+  // Cohorts: an oversubscribed joint-free batch is stepped as two slot ranges on two streams, each re-binned within itself, so
+  // that neither waits at a chunk boundary for the slowest wave of the whole batch.  cohortLo[c] ..
+  // cohortLo[c + 1] are cohort c's slots; stream2 serves cohort 1.
+  int nCohorts = 1;
+  int cohortLo[3] = {0, 0, 0};
+  hipStream_t stream2 = nullptr;
+  hipEvent_t evJoin = nullptr;
   size_t words = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -658,26 +667,35 @@ static int pick_cfg(const DevScene& S) {
   return -1;
 }
 
+// cohort < 0: all slots on the handle's stream, bracketed by the events (the handle's own pair if none are given);
+// cohort >= 0: that cohort's slot range on its stream, no events (the caller times the whole sequence)
 static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors,
                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, long long actStride = 0, uint8_t* lcdOut = nullptr,
-                       float* obsOut = nullptr) {
+                       float* obsOut = nullptr, int cohort = -1) {
   const int lanes = h->lanes;
-  dim3 grid((h->N + lanes - 1) / lanes), block(kBlock);
-  if (!e0) {
-    e0 = h->ev0;
-    e1 = h->ev1;
+  const int lo = cohort < 0 ? 0 : h->cohortLo[cohort];
+  const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
+  hipStream_t stream = cohort == 1 ? h->stream2 : h->stream;
+  dim3 grid((n + lanes - 1) / lanes), block(kBlock);
+  if (cohort < 0) {
+    if (!e0) {
+      e0 = h->ev0;
+      e1 = h->ev1;
+    }
+    HIPCHK(hipEventRecord(e0, stream));
   }
-  HIPCHK(hipEventRecord(e0, h->stream));
-  StepArgs A{h->dScene, h->st, h->N, h->eid, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny};
+  StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny};
   int idx = 0;
 #define X(a, b, c, d) \
-  if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, h->stream, A); \
+  if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \
   ++idx;
   BLCD_CONFIGS(X)
 #undef X
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e1, h->stream));
-  h->lastLaunches += 1;
+  if (cohort < 0) {
+    HIPCHK(hipEventRecord(e1, stream));
+    h->lastLaunches += 1;
+  }
   return BLCD_OK;
 }
 
@@ -694,17 +712,30 @@ static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* 
   return BLCD_OK;
 }
 
-// stable counting sort of slots by work class; swaps the state buffers
+// stable counting sort of slots by work class, within each cohort and on that cohort's stream; swaps the state buffers
 static int launch_rebin(blcd_handle h) {
-  int nBlocks = (h->N + kRebinBlock - 1) / kRebinBlock;
-  hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, h->stream, h->dScene, h->st, h->N, h->keys, h->binCounts, h->binMode);
-  hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->binCounts, h->binOffsets, nBlocks * kBins);
-  hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, h->stream, h->st, h->st2, h->N, (int)h->words, h->keys,
-                     h->binOffsets, h->eid, h->eid2, h->slotOf);
+  const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + 2;   // room for both cohorts' block counts (rounding)
+  for (int c = 0; c < h->nCohorts; ++c) {
+    const int lo = h->cohortLo[c], n = h->cohortLo[c + 1] - lo;
+    hipStream_t stream = c == 1 ? h->stream2 : h->stream;
+    const int nBlocks = (n + kRebinBlock - 1) / kRebinBlock;
+    int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
+    int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
+    hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->dScene, h->st + lo, h->N, n, h->keys + lo, counts,
+                       h->binMode);
+    hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, offsets, nBlocks * kBins);
+    hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->st + lo, h->st2 + lo, h->N, n, lo, (int)h->words,
+                       h->keys + lo, offsets, h->eid + lo, h->eid2 + lo, h->slotOf);
+  }
   HIPCHK(hipGetLastError());
   std::swap(h->st, h->st2);
   std::swap(h->eid, h->eid2);
   h->stepsSinceRebin = 0;
+  return BLCD_OK;
+}
+// everything outside the fused rollout runs on the handle's stream: let it see cohort 1's re-bin
+static int join_cohort_stream(blcd_handle h) {
+  if (h->nCohorts > 1) HIPCHK(hipStreamSynchronize(h->stream2));
   return BLCD_OK;
 }
 // Re-bin lazily, right before a launch, once a chunk's worth of env steps has passed since the last sort - whoever cut the
@@ -891,9 +922,9 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipMalloc((void**)&h->slotOf, (size_t)n_envs * sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->keys, (size_t)n_envs));
   {
-    int nBlocks = (n_envs + kRebinBlock - 1) / kRebinBlock;
-    HIPCHK(hipMalloc((void**)&h->binCounts, (size_t)nBlocks * kBins * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&h->binOffsets, (size_t)nBlocks * kBins * sizeof(int)));
+    int nBlocks = (n_envs + kRebinBlock - 1) / kRebinBlock + 2;
+    HIPCHK(hipMalloc((void**)&h->binCounts, (size_t)2 * nBlocks * kBins * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->binOffsets, (size_t)2 * nBlocks * kBins * sizeof(int)));
   }
   hipLaunchKernelGGL(iota_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, n_envs);
   HIPCHK(hipGetLastError());
@@ -924,6 +955,17 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     h->rebinEvery = (h->hostScene.nj == 0 && simds > 0 && (long long)n_envs > 64LL * simds) ? 1 : 0;
   }
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
+  h->cohortLo[1] = h->cohortLo[2] = n_envs;
+  {
+    int k = h->rebinEvery > 0 && !h->waveTimes ? 2 : 1;     // the re-binned (oversubscribed, joint-free) batches
+    if (const char* ev = getenv("BLCD_COHORTS")) k = atoi(ev) >= 2 && h->rebinEvery > 0 && !h->waveTimes ? 2 : 1;
+    if (k == 2) {
+      h->nCohorts = 2;
+      h->cohortLo[1] = ((n_envs / 2 + 63) / 64) * 64;       // whole waves in cohort 0
+      HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+      HIPCHK(hipEventCreate(&h->evJoin));
+    }
+  }
   if (const char* ev = getenv("BLCD_LANES")) {
     int l = atoi(ev);
     if (l >= 1 && l <= 64) h->lanes = l;
@@ -940,6 +982,11 @@ int blcd_destroy(blcd_handle h) {
     if (h->stage[k]) (void)hipFree(h->stage[k]);
   for (void* q : {(void*)h->dGoal, (void*)h->goalFs, (void*)h->goalLast, (void*)h->goalObs, (void*)h->goalLcd, (void*)h->goalCurLcd})
     if (q) (void)hipFree(q);
+  if (h->stream2) {
+    (void)hipStreamSynchronize(h->stream2);
+    (void)hipStreamDestroy(h->stream2);
+  }
+  if (h->evJoin) (void)hipEventDestroy(h->evJoin);
   if (h->dFaultAny) (void)hipFree(h->dFaultAny);
   if (h->dLut) (void)hipFree(h->dLut);
   if (h->dErr) (void)hipFree(h->dErr);
@@ -1028,6 +1075,7 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
   if ((rc = in_ptr(h, 0, actions, (size_t)h->N * h->hostScene.nact * sizeof(float), &dAct))) return rc;
   h->lastLaunches = 0;
   if ((rc = rebin_if_due(h))) return rc;
+  if ((rc = join_cohort_stream(h))) return rc;
   if ((rc = launch_step(h, (const float*)dAct, n_steps, 0, 0))) return rc;
   h->stepsSinceRebin += n_steps;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1054,6 +1102,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     h->evPool.push_back(ev);
   }
   int nLaunch = 0, fusedSteps = 0;
+  bool cohortTimed = false;
   if ((h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0) {
     // fused path: `chunk` env steps per launch, every wave runs its envs through the whole chunk and emits obs/LCD itself;
     // slots are re-binned by work class between chunks
@@ -1069,6 +1118,28 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
         chunk = c < 20.0f ? 20 : (c > 200.0f ? 200 : (int)c);
       }
     }
+    if (h->nCohorts > 1) {
+      // two cohorts, two streams, no barrier between chunks: cohort k's chunk i + 1 follows its own chunk i (and its own
+      // re-bin) only.  Timed as ONE sequence on the handle's stream: e0 before the first launch, e1 after stream2 has joined.
+      HIPCHK(hipEventRecord(h->evPool[0], h->stream));
+      HIPCHK(hipStreamWaitEvent(h->stream2, h->evPool[0], 0));   // staged inputs (actions copied on the handle's stream) first
+      for (int t = 0; t < T; t += chunk) {
+        int c = T - t < chunk ? T - t : chunk;
+        const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
+        if ((rc = rebin_if_due(h))) return rc;
+        for (int k = 0; k < h->nCohorts; ++k)
+          if ((rc = launch_step(h, a, c, 0, 0, nullptr, nullptr, (long long)h->N * nact, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr,
+                                dObs ? (float*)dObs + obsStep * t : nullptr, k)))
+            return rc;
+        h->stepsSinceRebin += c;
+        ++nLaunch;
+      }
+      HIPCHK(hipEventRecord(h->evJoin, h->stream2));
+      HIPCHK(hipStreamWaitEvent(h->stream, h->evJoin, 0));
+      HIPCHK(hipEventRecord(h->evPool[1], h->stream));
+      h->lastLaunches = nLaunch;
+      cohortTimed = true;
+    } else {
     for (int t = 0; t < T; t += chunk) {
       int c = T - t < chunk ? T - t : chunk;
       const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
@@ -1079,11 +1150,13 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
       h->stepsSinceRebin += c;
       ++nLaunch;
     }
+    }
     fusedSteps = T;
   } else {
     for (int t = 0; t < T; ++t) {
       const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
       if ((rc = rebin_if_due(h))) return rc;
+      if ((rc = join_cohort_stream(h))) return rc;
       if ((rc = launch_step(h, a, 1, 0, 0, h->evPool[2 * t], h->evPool[2 * t + 1]))) return rc;
       h->stepsSinceRebin += 1;
       ++nLaunch;
@@ -1094,11 +1167,16 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     }
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
   float total = 0.0f;  // step-kernel time only: each event pair brackets one step_kernel launch on this stream
-  for (int t = 0; t < nLaunch; ++t) {
-    float ms = 0.0f;
-    HIPCHK(hipEventElapsedTime(&ms, h->evPool[2 * t], h->evPool[2 * t + 1]));
-    total += ms;
+  if (cohortTimed) {   // cohorts: the whole overlapped sequence (both cohorts' launches and their re-bins), start to join
+    HIPCHK(hipEventElapsedTime(&total, h->evPool[0], h->evPool[1]));
+  } else {
+    for (int t = 0; t < nLaunch; ++t) {
+      float ms = 0.0f;
+      HIPCHK(hipEventElapsedTime(&ms, h->evPool[2 * t], h->evPool[2 * t + 1]));
+      total += ms;
+    }
   }
   h->lastMs = total;
   if (fusedSteps > 0) h->estMsPerStep = total / (float)fusedSteps;

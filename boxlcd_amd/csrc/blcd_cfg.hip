@@ -19,7 +19,7 @@
 namespace blcd {
 
 template <int NB, int NJ, int NP, int SH>
-__global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N,
+__global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, int nSlots,
                                                       const int* __restrict__ eid, const float* __restrict__ actions,
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
   if ((int)threadIdx.x >= lanes) return;
   int slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
-  if (slot >= N) return;
+  if (slot >= nSlots) return;
   const int e = eid[slot];
   Env<NB, NJ, NP, SH> env;
   env.load(S, st, N, slot);
@@ -145,7 +145,7 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 #define BLCD_NAME(p, a, b, c, d) BLCD_PASTE5(p, a, b, c, d)
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
-  hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.eid, A.actions,
+  hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
                      A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {

@@ -15,9 +15,10 @@ namespace blcd {
 
 struct StepArgs {
   const DevScene* S;
-  float* st;
-  int N;
-  const int* eid;
+  float* st;      // state base of the launch's slot range (= full base + first slot): field f of slot k at st[f * N + k]
+  int N;          // environments of the handle = stride between state fields
+  int nSlots;     // slots this launch covers (a cohort of a large batch, or all N)
+  const int* eid; // eid[k] = environment held by slot k of the range
   const float* actions;
   int nEnvSteps, nWorldSteps, setMotors, lanes;
   unsigned long long* waveTimes;

@@ -286,3 +286,29 @@ def test_rollout_results_do_not_depend_on_the_launch_chunking(name, monkeypatch)
       assert (lcd == ref[0]).all() and (obs == ref[1]).all()
       for a, b in zip(dump, ref[2]):
         assert (a == b).all()
+
+
+def test_cohorts_of_an_oversubscribed_batch_change_nothing(monkeypatch):
+  """A joint-free batch larger than 64 environments per SIMD is stepped as two slot ranges on two streams, each re-binned within
+  itself (no chunk-boundary barrier across the whole batch).  Frames, observations and final state equal the single-range run."""
+  n, T = 70_000, 60
+  outs = []
+  for name in ('Bounce', 'Object2'):
+    env, poses, sel = parity.make_batch(name, n, 9)
+    d = env.scene.desc
+    res = []
+    for cohorts in ('1', '2'):
+      monkeypatch.setenv('BLCD_COHORTS', cohorts)
+      h = Handle(d, n, 0)
+      h.reset(None, poses, sel)
+      lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+      obs = np.zeros((T, n, d.n_obs), np.float32)
+      h.rollout(None, T, lcd, obs)
+      h.step(None, 3)                                   # the single-stream path right after a cohort rollout
+      res.append((lcd, obs, [x.copy() for x in h.debug_dump()], h.faults().copy()))
+      h.close()
+    a, b = res
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), name
+    for x, y in zip(a[2], b[2]):
+      assert (x == y).all(), name
+    assert (a[3] == 0).all() and (b[3] == 0).all()
