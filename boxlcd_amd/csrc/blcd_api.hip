@@ -563,11 +563,12 @@ struct blcd_handle_s {
   int stepsSinceRebin = 0;
   // Cohorts: an oversubscribed joint-free batch is stepped as two slot ranges on two streams, each re-binned within itself, so
   // that neither waits at a chunk boundary for the slowest wave of the whole batch.  cohortLo[c] ..
-  // cohortLo[c + 1] are cohort c's slots; stream2 serves cohort 1.
+  // cohortLo[c + 1] are cohort c's slots; cohort 0 runs on the handle's stream, cohort c > 0 on cstream[c].
+  static constexpr int kMaxCohorts = 4;
   int nCohorts = 1;
-  int cohortLo[3] = {0, 0, 0};
-  hipStream_t stream2 = nullptr;
-  hipEvent_t evJoin = nullptr;
+  int cohortLo[kMaxCohorts + 1] = {0, 0, 0, 0, 0};
+  hipStream_t cstream[kMaxCohorts] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t evJoin[kMaxCohorts] = {nullptr, nullptr, nullptr, nullptr};
   size_t words = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -675,7 +676,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   const int lanes = h->lanes;
   const int lo = cohort < 0 ? 0 : h->cohortLo[cohort];
   const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
-  hipStream_t stream = cohort == 1 ? h->stream2 : h->stream;
+  hipStream_t stream = cohort > 0 ? h->cstream[cohort] : h->stream;
   dim3 grid((n + lanes - 1) / lanes), block(kBlock);
   if (cohort < 0) {
     if (!e0) {
@@ -714,10 +715,10 @@ static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* 
 
 // stable counting sort of slots by work class, within each cohort and on that cohort's stream; swaps the state buffers
 static int launch_rebin(blcd_handle h) {
-  const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + 2;   // room for both cohorts' block counts (rounding)
+  const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;   // room for every cohort's block counts (rounding)
   for (int c = 0; c < h->nCohorts; ++c) {
     const int lo = h->cohortLo[c], n = h->cohortLo[c + 1] - lo;
-    hipStream_t stream = c == 1 ? h->stream2 : h->stream;
+    hipStream_t stream = c > 0 ? h->cstream[c] : h->stream;
     const int nBlocks = (n + kRebinBlock - 1) / kRebinBlock;
     int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
     int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
@@ -735,7 +736,7 @@ static int launch_rebin(blcd_handle h) {
 }
 // everything outside the fused rollout runs on the handle's stream: let it see cohort 1's re-bin
 static int join_cohort_stream(blcd_handle h) {
-  if (h->nCohorts > 1) HIPCHK(hipStreamSynchronize(h->stream2));
+  for (int c = 1; c < h->nCohorts; ++c) HIPCHK(hipStreamSynchronize(h->cstream[c]));
   return BLCD_OK;
 }
 // Re-bin lazily, right before a launch, once a chunk's worth of env steps has passed since the last sort - whoever cut the
@@ -922,9 +923,9 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipMalloc((void**)&h->slotOf, (size_t)n_envs * sizeof(int)));
   HIPCHK(hipMalloc((void**)&h->keys, (size_t)n_envs));
   {
-    int nBlocks = (n_envs + kRebinBlock - 1) / kRebinBlock + 2;
-    HIPCHK(hipMalloc((void**)&h->binCounts, (size_t)2 * nBlocks * kBins * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&h->binOffsets, (size_t)2 * nBlocks * kBins * sizeof(int)));
+    int nBlocks = (n_envs + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;
+    HIPCHK(hipMalloc((void**)&h->binCounts, (size_t)blcd_handle_s::kMaxCohorts * nBlocks * kBins * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->binOffsets, (size_t)blcd_handle_s::kMaxCohorts * nBlocks * kBins * sizeof(int)));
   }
   hipLaunchKernelGGL(iota_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, n_envs);
   HIPCHK(hipGetLastError());
@@ -955,20 +956,21 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     h->rebinEvery = (h->hostScene.nj == 0 && simds > 0 && (long long)n_envs > 64LL * simds) ? 1 : 0;
   }
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
-  h->cohortLo[1] = h->cohortLo[2] = n_envs;
+  for (int c = 1; c <= blcd_handle_s::kMaxCohorts; ++c) h->cohortLo[c] = n_envs;
   {
     int k = h->rebinEvery > 0 && !h->waveTimes ? 2 : 1;     // the re-binned (oversubscribed, joint-free) batches
-    if (const char* ev = getenv("BLCD_COHORTS")) k = atoi(ev) >= 2 && h->rebinEvery > 0 && !h->waveTimes ? 2 : 1;
-    if (k == 2) {
-      h->nCohorts = 2;
-      h->cohortLo[1] = ((n_envs / 2 + 63) / 64) * 64;       // whole waves in cohort 0
-      HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-      HIPCHK(hipEventCreate(&h->evJoin));
+    if (const char* ev = getenv("BLCD_COHORTS")) {
+      int q = atoi(ev);
+      k = (q >= 2 && h->rebinEvery > 0 && !h->waveTimes) ? (q > blcd_handle_s::kMaxCohorts ? blcd_handle_s::kMaxCohorts : q) : 1;
     }
-  }
-  if (const char* ev = getenv("BLCD_LANES")) {
-    int l = atoi(ev);
-    if (l >= 1 && l <= 64) h->lanes = l;
+    if (k >= 2) {
+      h->nCohorts = k;
+      for (int c = 1; c < k; ++c) {
+        h->cohortLo[c] = (int)((((long long)n_envs * c / k + 63) / 64) * 64);       // whole waves per cohort
+        HIPCHK(hipStreamCreateWithFlags(&h->cstream[c], hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&h->evJoin[c]));
+      }
+    }
   }
   *out = h;
   return BLCD_OK;
@@ -982,11 +984,13 @@ int blcd_destroy(blcd_handle h) {
     if (h->stage[k]) (void)hipFree(h->stage[k]);
   for (void* q : {(void*)h->dGoal, (void*)h->goalFs, (void*)h->goalLast, (void*)h->goalObs, (void*)h->goalLcd, (void*)h->goalCurLcd})
     if (q) (void)hipFree(q);
-  if (h->stream2) {
-    (void)hipStreamSynchronize(h->stream2);
-    (void)hipStreamDestroy(h->stream2);
+  for (int c = 1; c < blcd_handle_s::kMaxCohorts; ++c) {
+    if (h->cstream[c]) {
+      (void)hipStreamSynchronize(h->cstream[c]);
+      (void)hipStreamDestroy(h->cstream[c]);
+    }
+    if (h->evJoin[c]) (void)hipEventDestroy(h->evJoin[c]);
   }
-  if (h->evJoin) (void)hipEventDestroy(h->evJoin);
   if (h->dFaultAny) (void)hipFree(h->dFaultAny);
   if (h->dLut) (void)hipFree(h->dLut);
   if (h->dErr) (void)hipFree(h->dErr);
@@ -1120,9 +1124,9 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     }
     if (h->nCohorts > 1) {
       // two cohorts, two streams, no barrier between chunks: cohort k's chunk i + 1 follows its own chunk i (and its own
-      // re-bin) only.  Timed as ONE sequence on the handle's stream: e0 before the first launch, e1 after stream2 has joined.
+      // re-bin) only.  Timed as ONE sequence on the handle's stream: e0 before the first launch, e1 after the other streams have joined.
       HIPCHK(hipEventRecord(h->evPool[0], h->stream));
-      HIPCHK(hipStreamWaitEvent(h->stream2, h->evPool[0], 0));   // staged inputs (actions copied on the handle's stream) first
+      for (int k = 1; k < h->nCohorts; ++k) HIPCHK(hipStreamWaitEvent(h->cstream[k], h->evPool[0], 0));   // staged inputs (copied on the handle's stream) first
       for (int t = 0; t < T; t += chunk) {
         int c = T - t < chunk ? T - t : chunk;
         const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
@@ -1134,8 +1138,10 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
         h->stepsSinceRebin += c;
         ++nLaunch;
       }
-      HIPCHK(hipEventRecord(h->evJoin, h->stream2));
-      HIPCHK(hipStreamWaitEvent(h->stream, h->evJoin, 0));
+      for (int k = 1; k < h->nCohorts; ++k) {
+        HIPCHK(hipEventRecord(h->evJoin[k], h->cstream[k]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->evJoin[k], 0));
+      }
       HIPCHK(hipEventRecord(h->evPool[1], h->stream));
       h->lastLaunches = nLaunch;
       cohortTimed = true;
@@ -1167,7 +1173,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
     }
   }
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
+  for (int c = 1; c < h->nCohorts; ++c) HIPCHK(hipStreamSynchronize(h->cstream[c]));
   float total = 0.0f;  // step-kernel time only: each event pair brackets one step_kernel launch on this stream
   if (cohortTimed) {   // cohorts: the whole overlapped sequence (both cohorts' launches and their re-bins), start to join
     HIPCHK(hipEventElapsedTime(&total, h->evPool[0], h->evPool[1]));
