@@ -189,6 +189,10 @@ def main():
     raise RuntimeError('bench.py needs a GPU: boxlcd_amd has no CPU path')
   torch.cuda.set_device(local)
   dev = torch.device('cuda', local)
+  if world > 1:
+    # the N>1 path feeds 20-step calls to overlap the gather: each call ends with a sync, so cohorts buy nothing there, and the
+    # gather's side stream + RCCL's own already occupy hardware queues (a fourth compute stream halves throughput)
+    os.environ.setdefault('BLCD_COHORTS', '1')
   N, T = args.envs, args.rollout_len
   overrides = {k: v for k, v in os.environ.items() if k.startswith('BLCD_') or k.startswith('BOXLCD_')}
 
