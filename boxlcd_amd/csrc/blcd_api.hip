@@ -948,6 +948,10 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
       int l = (n_envs + simds - 1) / simds;
       h->lanes = l < 16 ? 16 : (l > 64 ? 64 : l);   // below ~16 lanes the scratch footprint per useful lane costs more than the narrower union saves (Urchin-4096: 76 / 66 / 97 ms at 64 / 16 / 4 lanes)
     }
+    if (const char* ev = getenv("BLCD_LANES")) {   // experiments: overrides the automatic choice (placement only, results unchanged)
+      int l = atoi(ev);
+      if (l >= 1 && l <= 64) h->lanes = l;
+    }
     // Re-binning by work class.  It pays when environments sleep / fly freely (no joints keep them awake) AND the batch
     // oversubscribes the SIMDs, so that total wave time is what counts: Bounce-100k 1.66e9 with, 1.09e9 without.  With at most
     // one wave per SIMD the launch lasts as long as its slowest wave, a wave's cost is convex in its number of heavy lanes, and
@@ -963,10 +967,14 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
       int q = atoi(ev);
       k = (q >= 2 && h->rebinEvery > 0 && !h->waveTimes) ? (q > blcd_handle_s::kMaxCohorts ? blcd_handle_s::kMaxCohorts : q) : 1;
     }
+    // every cohort needs at least one whole wave of slots: small batches (BLCD_REBIN=1 / BLCD_COHORTS on a few environments)
+    // get fewer cohorts, down to the single range
+    while (k >= 2 && (long long)n_envs < 64LL * k) --k;
     if (k >= 2) {
       h->nCohorts = k;
       for (int c = 1; c < k; ++c) {
-        h->cohortLo[c] = (int)((((long long)n_envs * c / k + 63) / 64) * 64);       // whole waves per cohort
+        long long lo = (((long long)n_envs * c / k + 63) / 64) * 64;                // whole waves per cohort
+        h->cohortLo[c] = (int)(lo < n_envs ? lo : n_envs);
         HIPCHK(hipStreamCreateWithFlags(&h->cstream[c], hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&h->evJoin[c]));
       }

@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_build', 'libb2oracle.so')
+# B2O_LIB: an alternative build of the same sources (tools/replay_gifs.py --builds: FMA-contracting experiments)
+LIB_PATH = os.environ.get('B2O_LIB') or os.path.join(_HERE, '_build', 'libb2oracle.so')
 BODY_F, JOINT_F, PAIR_F = 12, 5, 18
 _lib = None
 _ellipse_rgb_lut = None

@@ -12,7 +12,7 @@ from oracle import pyb2o
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name,n,steps', [('Dropbox', 256, 60), ('Bounce', 256, 200), ('Object2', 256, 200),
+@pytest.mark.parametrize('name,n,steps', [('Dropbox', 256, 200), ('Bounce', 256, 200), ('Object2', 256, 200),
                                           ('Urchin', 128, 200), ('LuxoBall', 128, 200)])
 def test_baseline_configs_bit_exact_per_world_step(name, n, steps):
   cnt, msgs = parity.run_substep_parity(name, n, steps, seed=11)
@@ -89,8 +89,16 @@ def test_recordings_replayed_on_device_from_recorder_inputs():
     lcd = np.zeros((T, 1, d.lcd_h, d.lcd_w), np.uint8)
     h.rollout(acts, T, lcd_out=lcd)
     bad = [int((lcd[t, 0] != exp[t]).sum()) for t in range(T)]
-    obad, _ = R.replay(gif, pyb2o, want_rgb=False)
+    o = pyb2o.OracleEnv(d)
+    o.reset(np.asarray(P, np.float32), sel)
+    obad = []
+    for t in range(T):
+      o.step(acts[t, 0])
+      obad.append(int((o.render() != exp[t]).sum()))
     assert bad == obad, gif                                   # device == oracle, frame by frame
+    # north_star's pose tolerance (1e-4 on positions / angles) against the oracle at the end of the recording: met with zero error
+    dev, ora = h.debug_dump()[0][0], o.dump()[0]
+    assert np.abs(dev[:, :3] - ora[:, :3]).max() <= 1e-4 and (dev == ora).all(), gif
     if gif in ('Dropbox', 'Bounce', 'Bounce2', 'Object2', 'Object2_circles', 'Object2_cubes', 'UrchinBall', 'UrchinCube'):
       assert sum(bad) == 0, (gif, R.summary(bad))
     h.close()
@@ -207,10 +215,12 @@ def test_state_injection_right_after_reset_keeps_contact_order(name):
   h.close()
 
 
-@pytest.mark.parametrize('name,n,T', [('Urchin', 50_000, 40), ('LuxoBall', 50_000, 30), ('Object2', 200_000, 60)])
+@pytest.mark.parametrize('name,n,T', [('Urchin', 50_000, 200), ('LuxoBall', 50_000, 200), ('Object2', 200_000, 200),
+                                     ('Dropbox', 100_000, 200), ('Bounce', 100_000, 200)])
 def test_full_size_baseline_batches(name, n, T):
-  """BASELINE configs[2..4] at their full batch sizes (one GPU's worth; the 8-GPU configs shard exactly this): fused rollout,
-  no faults, physical bounds, every environment drawn, and a 64-environment sample of the batch against the oracle."""
+  """Every BASELINE workload at its full batch size AND its stated length (200 env-steps; one GPU's worth - the 8-GPU configs
+  shard exactly this): fused rollout, no faults, physical bounds, every environment drawn, and a 64-environment sample of the
+  batch against the oracle at the final step."""
   env = B.BatchedWorldEnv(name, n, seed=31)
   poses, sel = env.sample_initial(n)
   acts = env.sample_actions(T)
@@ -312,3 +322,30 @@ def test_cohorts_of_an_oversubscribed_batch_change_nothing(monkeypatch):
     for x, y in zip(a[2], b[2]):
       assert (x == y).all(), name
     assert (a[3] == 0).all() and (b[3] == 0).all()
+
+
+@pytest.mark.parametrize('n', [10, 64, 65, 130, 255])
+def test_rebin_and_cohort_knobs_on_small_batches_change_nothing(monkeypatch, n):
+  """BLCD_REBIN=1 / BLCD_COHORTS=4 are documented as placement-only knobs: on batches too small to give every cohort a whole wave
+  the handle falls back to fewer cohorts (never an empty or out-of-range slot range) and results equal the default run."""
+  T = 40
+  env, poses, sel = parity.make_batch('Object2', n, 3)
+  d = env.scene.desc
+  res = []
+  for knobs in ({}, {'BLCD_REBIN': '1'}, {'BLCD_REBIN': '1', 'BLCD_COHORTS': '4'}):
+    for k in ('BLCD_REBIN', 'BLCD_COHORTS'):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in knobs.items():
+      monkeypatch.setenv(k, v)
+    h = Handle(d, n, 0)
+    h.reset(None, poses, sel)
+    lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+    obs = np.zeros((T, n, d.n_obs), np.float32)
+    h.rollout(None, T, lcd, obs)
+    res.append((lcd, obs, [x.copy() for x in h.debug_dump()]))
+    assert not h.faults().any()
+    h.close()
+  for b in res[1:]:
+    assert (res[0][0] == b[0]).all() and (res[0][1] == b[1]).all()
+    for x, y in zip(res[0][2], b[2]):
+      assert (x == y).all()

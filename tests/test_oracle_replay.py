@@ -43,20 +43,23 @@ def test_box2d_230_forms_are_what_the_recordings_need(oracle):
     assert R.summary(R.replay('UrchinBall', oracle, want_rgb=False)[0])['exact'] < 150
 
 
-def test_open_recordings_tracking(oracle):
-  """NOT reproduced to the end (tracked, not hidden): Urchin.gif, Luxo.gif, LuxoBall.gif, LuxoCube.gif.  They are exact at
-  25.6 px/unit for their first 17 / 66 / 57 / 33 frames and then drift (chaos amplifies an ulp-level difference); all four
-  score better with the glibc >= 2.28 sincos than the seven exact recordings do, i.e. they look like they were recorded on a
-  second machine (newer libm) with one more, unidentified, ulp-level difference — no switch combination reproduces them
-  (DESIGN.md §2).  Luxo frame 37 / LuxoBall frame 38 additionally differ by the 6-px degenerate foot polygon at (0,0),
-  which the recordings' Pillow draws and no characterised raster variant does."""
-  s = R.summary(R.replay('Urchin', oracle)[1]);   assert s['first_miss'] >= 17, s
-  bl, br = R.replay('Luxo', oracle)
-  assert R.summary(bl)['exact'] >= 95 and bl[37] == 6 and R.summary(br)['first_miss'] >= 66
-  bl, br = R.replay('LuxoBall', oracle)
-  assert R.summary(bl)['exact'] >= 100 and bl[38] == 6 and R.summary(br)['first_miss'] >= 57
-  with oracle.variants(sincos=0):
-    s = R.summary(R.replay('LuxoCube', oracle, want_rgb=False)[0]);   assert s['exact'] >= 132, s
+def test_four_recordings_pin_the_oracle_only_for_a_prefix(oracle):
+  """PARITY IS OPEN HERE, and this test states exactly how far it is closed: Urchin.gif, Luxo.gif, LuxoBall.gif and
+  LuxoCube.gif are reproduced at 25.6 px/unit for their first 17 / 66 / 57 / 33 frames ONLY; past those frames the oracle
+  (and therefore the HIP path) is NOT pinned by them.  BASELINE configs[2] (Urchin) and [3] (LuxoBall) are among the four.
+  Every candidate tried in rounds 2-3 (all 48 combinations of the five oracle switches, velocity/position iteration counts,
+  a correctly rounded sincos, four FMA-contracting builds with GCC and clang at -O2/-O3) is tabulated in
+  profiles/r03_open_recordings_sweep.md and DESIGN.md 2.1: none reproduces any of the four to its end.
+  Luxo frame 37 / LuxoBall frame 38 additionally differ by the degenerate foot polygon (0,0),(5,0),(5,0),(0,0), which the
+  recordings' Pillow draws as a 6-px line although it draws none of the 12 other degenerate polygons in the recordings."""
+  for gif, first_miss in (('Urchin', 17), ('Luxo', 66), ('LuxoBall', 57), ('LuxoCube', 33)):
+    bl, br = R.replay(gif, oracle)
+    assert R.summary(br)['first_miss'] == first_miss, (gif, R.summary(br))     # pinned for exactly this prefix
+    assert all(b == 0 for b in bl[:first_miss]) or gif in ('Luxo', 'LuxoBall'), gif
+    if gif == 'Luxo':
+      assert [i for i, b in enumerate(bl[:66]) if b] == [37] and bl[37] == 6
+    if gif == 'LuxoBall':
+      assert [i for i, b in enumerate(bl[:57]) if b] == [38] and bl[38] == 6
 
 
 def test_seed7_sample_is_the_recordings_start(oracle):
