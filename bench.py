@@ -94,7 +94,7 @@ class Workload:
   def enable_gather(self, world):
     from boxlcd_amd import dist as bdist
     c = min(self.chunk, self.T)
-    self.gatherer = bdist.ChunkGatherer(world, [self.lcd[:c], self.obs[:c]])
+    self.gatherer = bdist.ChunkGatherer(world, [self.lcd[:c], self.obs[:c]], binary=[True, False])   # mode-1 LCD frames are 0/1 bytes
 
   def rollout(self):
     h = self.h

@@ -63,15 +63,21 @@ class ChunkGatherer:
   `producer` is the stream the chunk was written on (the handle's stream); the returned event marks the end of the gather:
   make the producer wait on it before it rewrites the source region (`producer.wait_event(ev)`)."""
 
-  def __init__(self, world, templates, nbuf=2, pack_bits=True):
+  def __init__(self, world, templates, nbuf=2, binary=None):
+    """`binary[i]` = True declares tensor i to hold only 0/1 bytes (LCD frames in mode '1'): it is bit-packed for the wire.
+    Packing keeps bit 0 of every byte, so it is strictly opt-in - RGB frames or LCDs scaled to 255 must not be declared."""
     import torch
     self.world = world
     self.cuda = templates[0].is_cuda
+    binary = [False] * len(templates) if binary is None else list(binary)
+    assert len(binary) == len(templates)
+    for t, b in zip(templates, binary):
+      assert not b or (t.dtype == torch.uint8 and t.numel() % 8 == 0), 'binary tensors must be uint8 with a multiple of 8 elements'
     self.bufs = [[torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in templates] for _ in range(nbuf)]
     self.k = 0
     self.stream = torch.cuda.Stream(device=templates[0].device) if self.cuda else None
     # packed staging for the uint8 tensors (GPU only: the kernels live in the HIP library)
-    self.packed = [self.cuda and pack_bits and t.dtype == torch.uint8 and t.numel() % 8 == 0 for t in templates]
+    self.packed = [self.cuda and b for b in binary]
     self.pk_src = [torch.empty(t.numel() // 8, dtype=torch.uint8, device=t.device) if p else None for t, p in zip(templates, self.packed)]
     self.pk_dst = [torch.empty(world * t.numel() // 8, dtype=torch.uint8, device=t.device) if p else None for t, p in zip(templates, self.packed)]
 
@@ -91,7 +97,9 @@ class ChunkGatherer:
       self.stream.wait_event(ready)
       sp = self.stream.cuda_stream
       for i, (d, s) in enumerate(zip(dst, srcs)):
+        assert s.is_contiguous(), 'gather sources must be contiguous'
         if self.packed[i]:
+          assert s.data_ptr() % 8 == 0, 'bit-packed sources must be 8-byte aligned'
           _lib.pack_bits(s, self.pk_src[i], sp)
           dist.all_gather_into_tensor(self.pk_dst[i], self.pk_src[i])
           _lib.unpack_bits(self.pk_dst[i], d, sp)

@@ -382,12 +382,30 @@ class BatchedWorldEnv(_EnvSpec):
     proprio = fs[:, self.pobs_idxs] if self.pobs_size != 0 else np.zeros((self.num_envs, 1), np.float32)
     return {'full_state': fs, 'proprio': proprio, 'lcd': lcd.astype(bool)}
 
+  def _step_handle(self, a):
+    """blcd_step completes the step for EVERY environment and then reports BLCD_ERR_ENV_FAULT if any environment carries a
+    device fault flag (contact-slot overflow, non-finite state).  One bad environment must not abort a 100k batch: the
+    bookkeeping goes on, the flags stay readable through `faults()` / `infos[i]['fault']` until those envs are reset."""
+    from ._lib import EnvFaultError
+    try:
+      self._handle().step(a, 1)
+      self._any_fault = False
+    except EnvFaultError:
+      self._any_fault = True
+
+  def faults(self):
+    """uint32 [N] device fault flags (0 = healthy); sticky until the environment is reset."""
+    return self._handle().faults()
+
   def step(self, actions):
     a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_size))
-    self._handle().step(a, 1)
+    self._step_handle(a)
     self.ep_t += 1
     done = self.ep_t >= self.G.ep_len
     infos = [{'timeout': bool(d)} for d in done]
+    if self._any_fault:
+      for i in np.nonzero(self.faults())[0]:
+        infos[int(i)]['fault'] = True
     return self._obs(), np.zeros(self.num_envs, np.float64), done, infos
 
   # ---- device-resident surface: torch CUDA tensors in and out, no host copies, no per-env Python objects -----------------
@@ -434,7 +452,7 @@ class BatchedWorldEnv(_EnvSpec):
     tb = self._torch_bufs()
     a = actions.contiguous() if actions.dtype == tb['full_state'].dtype else actions.float().contiguous()
     assert a.is_cuda and tuple(a.shape) == (self.num_envs, self.act_size)
-    self._handle().step(a, 1)
+    self._step_handle(a)          # a faulted environment does not abort the batch: see faults()
     tb['ep_t'] += 1
     self.ep_t += 1
     done = tb['ep_t'] >= int(self.G.ep_len)

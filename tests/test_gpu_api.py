@@ -216,7 +216,7 @@ def _gather_rank(rank, world, port, q):
   bdist.init_from_env('gloo')                      # both ranks share cuda:0 here; on a node it is nccl, one GPU per rank
   torch.cuda.set_device(0)
   Tc, n = 4, 96
-  g = bdist.ChunkGatherer(world, [torch.empty((Tc, n, 16, 16), dtype=torch.uint8, device='cuda'), torch.empty((Tc, n, 4), device='cuda')])
+  g = bdist.ChunkGatherer(world, [torch.empty((Tc, n, 16, 16), dtype=torch.uint8, device='cuda'), torch.empty((Tc, n, 4), device='cuda')], binary=[True, False])
   ok = True
   for chunk in range(3):
     gen = torch.Generator(device='cuda'); gen.manual_seed(100 * chunk + rank)
