@@ -549,6 +549,9 @@ struct blcd_handle_s {
   int *binCounts = nullptr, *binOffsets = nullptr;
   int rebinEvery = 0;       // 0 = never; k = after every k-th env step
   int lanes = 64;           // environments per wave in step_kernel (BLCD_LANES)
+  // environment-level scheduling of fused chunks (joint-free classes): passes per chunk (1 = off) and the most
+  // lanes of a wave that may still be sweeping for those lanes to be suspended (BLCD_YIELD_PASSES, BLCD_YIELD_LANES)
+  int yieldPasses = 1, yieldMaxLanes = 0;
   // goal epilogue (blcd_goal_*): device-resident goals, previous deltas and scratch observation buffers
   blcd_goal_desc goal{};
   bool goalSet = false;
@@ -670,9 +673,12 @@ static int pick_cfg(const DevScene& S) {
 
 // cohort < 0: all slots on the handle's stream, bracketed by the events (the handle's own pair if none are given);
 // cohort >= 0: that cohort's slot range on its stream, no events (the caller times the whole sequence)
+// pass / nPasses: a fused chunk is stepped in nPasses launches (environment-level scheduling): in all but the last
+// one a lane may suspend a straggling environment, which the next pass resumes; e0 is recorded before the first pass and e1
+// after the last, so a "launch" of the timing code stays one chunk of the batch
 static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors,
                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, long long actStride = 0, uint8_t* lcdOut = nullptr,
-                       float* obsOut = nullptr, int cohort = -1) {
+                       float* obsOut = nullptr, int cohort = -1, int pass = 0, int nPasses = 1) {
   const int lanes = h->lanes;
   const int lo = cohort < 0 ? 0 : h->cohortLo[cohort];
   const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
@@ -683,9 +689,10 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
       e0 = h->ev0;
       e1 = h->ev1;
     }
-    HIPCHK(hipEventRecord(e0, stream));
+    if (pass == 0) HIPCHK(hipEventRecord(e0, stream));
   }
-  StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny};
+  StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
+             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \
@@ -693,7 +700,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   BLCD_CONFIGS(X)
 #undef X
   HIPCHK(hipGetLastError());
-  if (cohort < 0) {
+  if (cohort < 0 && pass + 1 == nPasses) {
     HIPCHK(hipEventRecord(e1, stream));
     h->lastLaunches += 1;
   }
@@ -960,6 +967,19 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     h->rebinEvery = (h->hostScene.nj == 0 && simds > 0 && (long long)n_envs > 64LL * simds) ? 1 : 0;
   }
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
+  if (h->hostScene.nj == 0 && h->hostScene.nb <= 7 && h->hostScene.velIters > kYieldSweeps) {
+    h->yieldPasses = 3;
+    h->yieldMaxLanes = 24;
+    if (const char* ev = getenv("BLCD_YIELD_PASSES")) {
+      int q = atoi(ev);
+      h->yieldPasses = q < 1 ? 1 : (q > 8 ? 8 : q);
+    }
+    if (const char* ev = getenv("BLCD_YIELD_LANES")) {
+      int q = atoi(ev);
+      h->yieldMaxLanes = q < 0 ? 0 : (q > 64 ? 64 : q);
+    }
+    if (h->yieldPasses == 1 || h->yieldMaxLanes == 0) h->yieldPasses = 1, h->yieldMaxLanes = 0;
+  }
   for (int c = 1; c <= blcd_handle_s::kMaxCohorts; ++c) h->cohortLo[c] = n_envs;
   {
     int k = h->rebinEvery > 0 && !h->waveTimes ? 2 : 1;     // the re-binned (oversubscribed, joint-free) batches
@@ -1139,10 +1159,11 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
         int c = T - t < chunk ? T - t : chunk;
         const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
         if ((rc = rebin_if_due(h))) return rc;
-        for (int k = 0; k < h->nCohorts; ++k)
-          if ((rc = launch_step(h, a, c, 0, 0, nullptr, nullptr, (long long)h->N * nact, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr,
-                                dObs ? (float*)dObs + obsStep * t : nullptr, k)))
-            return rc;
+        for (int pass = 0; pass < h->yieldPasses; ++pass)
+          for (int k = 0; k < h->nCohorts; ++k)
+            if ((rc = launch_step(h, a, c, 0, 0, nullptr, nullptr, (long long)h->N * nact, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr,
+                                  dObs ? (float*)dObs + obsStep * t : nullptr, k, pass, h->yieldPasses)))
+              return rc;
         h->stepsSinceRebin += c;
         ++nLaunch;
       }
@@ -1158,9 +1179,10 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
       int c = T - t < chunk ? T - t : chunk;
       const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
       if ((rc = rebin_if_due(h))) return rc;
-      if ((rc = launch_step(h, a, c, 0, 0, h->evPool[2 * nLaunch], h->evPool[2 * nLaunch + 1], (long long)h->N * nact,
-                            dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr, dObs ? (float*)dObs + obsStep * t : nullptr)))
-        return rc;
+      for (int pass = 0; pass < h->yieldPasses; ++pass)
+        if ((rc = launch_step(h, a, c, 0, 0, h->evPool[2 * nLaunch], h->evPool[2 * nLaunch + 1], (long long)h->N * nact,
+                              dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr, dObs ? (float*)dObs + obsStep * t : nullptr, -1, pass, h->yieldPasses)))
+          return rc;
       h->stepsSinceRebin += c;
       ++nLaunch;
     }

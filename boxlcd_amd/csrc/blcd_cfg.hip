@@ -23,7 +23,8 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       const int* __restrict__ eid, const float* __restrict__ actions,
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
-                                                      uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny) {
+                                                      uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
+                                                      int pass, int yieldMaxLanes) {
   uint32_t* const ldsRows = Env<NB, NJ, NP, SH>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
@@ -32,49 +33,96 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   int slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
   if (slot >= nSlots) return;
   const int e = eid[slot];
-  Env<NB, NJ, NP, SH> env;
+  using EnvT = Env<NB, NJ, NP, SH>;
+  // Progress inside a fused chunk (environment-level scheduling): a chunk is stepped in `passes`; pass 0 starts
+  // every environment at env-step 0, a later pass picks each environment up where the previous one left it - finished (the lane
+  // idles), or suspended in the velocity sweeps of one of its islands (the lane resumes that world step first).
+  float* const progWord = st + (size_t)schedWordOffset(S->nb, S->nj, S->np) * N + slot;
+  uint32_t prog = (nEnvSteps > 0 && pass > 0) ? __float_as_uint(*progWord) : 0u;
+  int t = (int)(prog & 0xffu), sub = (int)((prog >> 8) & 3u);
+  bool live = t < nEnvSteps;
+  if (nEnvSteps > 0 && !__any(live)) return;     // the whole wave finished the chunk in an earlier pass
+  const bool fullWave = __ballot(1) == ~0ull;    // every lane of the wave holds an environment (the coalesced frame store needs all 64)
+  EnvT env;
   env.load(S, st, N, slot);
   env.profOn = waveTimes != nullptr;
+  env.velMask = (prog >> 10) & 0x7fu;
+  env.islandedMask = (prog >> 17) & 0x7fu;
+  env.yieldMaxLanes = yieldMaxLanes;
 #ifdef BLCD_ABLATION
   if (S->dbgSkip & 8) nEnvSteps = nWorldSteps = 0;
 #endif
   if (nEnvSteps > 0) {
     // Fused rollout: this wave advances its environments through all nEnvSteps on its own (no grid-wide barrier between
-    // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.
+    // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.  Lanes progress
+    // at their own pace: a lane whose environment suspends (worldStep returns true) idles until the next pass.
     const size_t lcdRow = (size_t)S->lcdH * S->lcdW;
-    for (int t = 0; t < nEnvSteps; ++t) {
-      env.setMotorSpeeds(actions ? actions + (size_t)t * actStride : nullptr, N, e);
-      for (int k = 0; k < S->substeps; ++k) env.worldStep();
-      if (lcdOut || obsOut) {
+    const bool mayYield = EnvT::kCanYield && yieldMaxLanes > 0;
+    bool resume = EnvT::kCanYield && env.velMask != 0;
+    while (__any(live)) {
+      bool emitNow = false;
+      if (live) {
+        bool suspended = false;
+        if (resume) {
+          env.worldStepResume();
+          resume = false;
+        } else {
+          if (sub == 0) env.setMotorSpeeds(actions ? actions + (size_t)t * actStride : nullptr, N, e);
+          suspended = env.worldStep(mayYield);
+        }
+        if (suspended) live = false;
+        else if (++sub == S->substeps) {
+          sub = 0;
+          emitNow = true;
+        }
+      }
+      if ((lcdOut || obsOut) && __any(emitNow)) {
         auto body = [&](int i, Vec2* p, float* a, int* sel) {
           const int bi = NB == 1 ? 0 : i;  // static index for single-body scenes (keeps env in registers)
           *p = env.xfp[bi];
           *a = env.a[bi];
           *sel = env.sel[bi];
         };
-        bool ok;
-        if (lcdOut && S->lcdW == 16 && __ballot(1) == ~0ull) {   // full waves only: a frame needs all 64 lanes to write it
+        bool ok = true;
+        if (lcdOut && S->lcdW == 16 && fullWave) {
           // 16x16 frames: 256 B = one dword per lane.  Writing each lane's own frame row by row makes every store touch 64
-          // different cache lines; instead the lanes park their 16 row masks in LDS and the wave writes one whole frame per
-          // store instruction (fully coalesced), frame k being the environment held by lane k.
-          uint32_t rows[16];
-          ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
+          // different cache lines; instead the emitting lanes park their 16 row masks in LDS and the WHOLE wave writes one frame
+          // per store instruction (fully coalesced): frame k = the environment held by lane k, at that lane's own env-step.
           const int lane = (int)threadIdx.x;
+          if (emitNow) {
+            uint32_t rows[16];
+            ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
 #pragma unroll
-          for (int y = 0; y < 16; ++y) ldsRows[lane * 17 + y] = rows[y];
+            for (int y = 0; y < 16; ++y) ldsRows[lane * 17 + y] = rows[y];
+          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          uint8_t* frames = lcdOut + (size_t)t * N * lcdRow;
           const int row = lane >> 2, x0 = (lane & 3) * 4;   // this lane's 4 pixels of any frame
-          for (int k = 0; k < 64; ++k) {
-            const int ek = __builtin_amdgcn_readlane(e, k);
-            const uint32_t m = ldsRows[k * 17 + row];
-            const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
-            *reinterpret_cast<uint32_t*>(frames + (size_t)ek * 256 + 4 * lane) = px;
+          unsigned long long em = __ballot(emitNow);
+          if (em == ~0ull) {
+            uint8_t* frames = lcdOut + (size_t)__builtin_amdgcn_readfirstlane(t) * N * lcdRow;   // lanes in step: one base
+            const bool sameT = __all(t == __builtin_amdgcn_readfirstlane(t));
+            for (int k = 0; k < 64; ++k) {
+              const int ek = __builtin_amdgcn_readlane(e, k);
+              if (!sameT) frames = lcdOut + (size_t)__builtin_amdgcn_readlane(t, k) * N * lcdRow;
+              const uint32_t m = ldsRows[k * 17 + row];
+              const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+              *reinterpret_cast<uint32_t*>(frames + (size_t)ek * 256 + 4 * lane) = px;
+            }
+          } else {
+            while (em) {
+              const int k = __ffsll((long long)em) - 1;
+              em &= em - 1;
+              const int ek = __builtin_amdgcn_readlane(e, k);
+              const int tk = __builtin_amdgcn_readlane(t, k);
+              const uint32_t m = ldsRows[k * 17 + row];
+              const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+              *reinterpret_cast<uint32_t*>(lcdOut + ((size_t)tk * N + ek) * 256 + 4 * lane) = px;
+            }
           }
           __builtin_amdgcn_wave_barrier();
-        } else {
+        } else if (emitNow) {
           float* obsRowOut = obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr;
           uint8_t* lcdRowOut = lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr;
           bool tall = false;
@@ -84,7 +132,9 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
         }
         if (!ok) env.fault |= FAULT_ELLIPSE;
       }
+      if (emitNow && ++t >= nEnvSteps) live = false;
     }
+    *progWord = __uint_as_float((uint32_t)t | ((uint32_t)sub << 8) | (env.velMask << 10) | (env.islandedMask << 17));
   } else {
     if (setMotors) env.setMotorSpeeds(actions, N, e);
     for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
@@ -146,7 +196,7 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny);
+                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {
   hipLaunchKernelGGL((set_poses_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(64), 0, stream, A.S, A.st, A.N, A.slotOf, A.idxs, A.n,

@@ -26,6 +26,8 @@ struct StepArgs {
   uint8_t* lcdOut;
   float* obsOut;
   int* faultAny;   // set to 1 by any lane whose environment carries a fault flag after the launch
+  int pass;           // fused chunks are stepped in passes: 0 starts the chunk, > 0 resumes it (progress word of every slot)
+  int yieldMaxLanes;  // > 0: a lane may suspend its environment when at most this many lanes of its wave still sweep (never in the last pass)
 };
 struct SetPosesArgs {
   const DevScene* S;

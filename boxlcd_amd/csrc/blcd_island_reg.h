@@ -800,11 +800,14 @@ struct RegIsland {
   }
 
   // all velocity sweeps, with the bit-safe early exits of the generic path (fixed point; short cycle for joint-free islands)
-  __device__ __forceinline__ int velocitySweeps(int velIters, float dt, unsigned long long* waveIters = nullptr) {
+  // startIt / yieldAt / yieldMaxLanes: environment-level scheduling (Env::islandSolve): a joint-free island that is still
+  // sweeping after `yieldAt` sweeps while at most yieldMaxLanes lanes of the wave are, stops there and sets *yielded
+  __device__ __forceinline__ int velocitySweeps(int velIters, float dt, unsigned long long* waveIters = nullptr, int startIt = 0,
+                                                int yieldAt = 0, int yieldMaxLanes = 0, bool* yielded = nullptr) {
     int done = 0;
     const bool watch = nj == 0 && nc > 0;
     CycRow cyc[kCycP];
-    for (int it = 0; it < velIters; ++it) {
+    for (int it = startIt; it < velIters; ++it) {
       bool changed = false;
 #ifdef BLCD_PROF_TOI2
       if (waveIters && (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) *waveIters += 1;   // wave-level iterations
@@ -838,6 +841,12 @@ struct RegIsland {
         }
         if (found) break;
         rSet(cyc, it & (kCycP - 1), cur);
+      }
+      if (yieldAt > 0 && it == yieldAt - 1 && velIters > yieldAt) {
+        if (__popcll(__ballot(1)) <= yieldMaxLanes) {
+          *yielded = true;
+          break;
+        }
       }
     }
     return done;

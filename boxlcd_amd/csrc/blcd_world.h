@@ -92,9 +92,17 @@ struct DevScene {
   DevObs obs[96];
 };
 
-BLCD_HD static inline int stateWords(int nb, int nj, int np) {
+// Scheduling words, appended after everything else (so no other offset moves): one progress word (env-step and sub-step
+// reached inside the current fused chunk, seeds of the islands suspended in their velocity sweeps, bodies that were in an
+// island this world step) and, per body, the velocity a suspended island's sweeps had reached (v.x v.y w).  See Env::solve.
+BLCD_HD static inline int schedWordOffset(int nb, int nj, int np) {
   return nb * kBodyFields + np * kPairFields + nj * kJointFields + kWorldFields + (np + 3) / 4;
 }
+BLCD_HD static inline int stateWords(int nb, int nj, int np) { return schedWordOffset(nb, nj, np) + 1 + 3 * nb; }
+// A lane whose joint-free island has not converged after this many velocity sweeps (= the window of the short-cycle detector)
+// may suspend its environment instead of dragging the wave through the remaining <= 156 sweeps (scheduling only: the
+// environment resumes in a later pass of the same chunk at exactly this sweep, with exactly this solver state)
+constexpr int kYieldSweeps = 24;
 
 struct VCPoint {
   Vec2 rA, rB;
@@ -315,11 +323,24 @@ struct Env {
 
   uint8_t ij[NJ > 0 ? NJ : 1];
 
+  // --- environment-level scheduling (fused rollouts) ---
+  static constexpr bool kCanYield = NJ == 0 && NB <= 7;   // joint-free classes: their sweeps have an early exit that stragglers miss
+  float* gst;            // this slot's column of the state array (word f at gst[f * gN]): suspended velocities go straight there
+  int gN;
+  uint32_t velMask;      // seeds of the islands suspended in their velocity sweeps
+  uint32_t islandedMask; // bodies that were in an island when the world step was suspended (SynchronizeFixtures still owed)
+  int yieldMaxLanes;     // suspend only when at most this many lanes of the wave are still sweeping (0 = never)
+
   // ------------------------------------------------------------------------------------------------
   // SoA state <-> thread
   // ------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void load(const DevScene* scene, const float* __restrict__ st, int N, int e) {
     S = scene;
+    gst = const_cast<float*>(st) + e;
+    gN = N;
+    velMask = 0;
+    islandedMask = 0;
+    yieldMaxLanes = 0;
     if constexpr (kGenLds) {   // 6 words x NB bodies x 64 lanes (30 KB for NB = 20)
       __shared__ float blk[6 * NB * 64];
       LdsFloat* base = (LdsFloat*)blk;
@@ -1402,11 +1423,12 @@ struct Env {
       }
     }
   }
-  __device__ __forceinline__ void velocitySweeps(uint32_t ibmask, int nic, int nij, float h) {
+  // returns true when the lane suspends at sweep kYieldSweeps (only asked of joint-free islands, see kCanYield)
+  __device__ __forceinline__ bool velocitySweeps(uint32_t ibmask, int nic, int nij, float h, int startIt = 0, bool mayYield = false) {
     const int velIters = S->velIters;
     bool watch = nij == 0 && nic > 0 && nic <= kCycNC && (ibmask >> kCycNB) == 0;
     CycRow cyc[kCycP];
-    for (int it = 0; it < velIters; ++it) {
+    for (int it = startIt; it < velIters; ++it) {
       bool changed = false;
       for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
       changed = csSolveVelocityConstraints(nic) || changed;
@@ -1431,8 +1453,16 @@ struct Env {
         if (found) break;
         selSet(cyc, it & (kCycP - 1), cur);
       }
+      if (mayYield && it == kYieldSweeps - 1 && velIters > kYieldSweeps) {
+        // the lanes that reach this line are the wave's stragglers (everyone else left the loop at a fixed point / short cycle)
+        if (__popcll(__ballot(1)) <= yieldMaxLanes) return true;
+      }
     }
+    return false;
   }
+
+  // suspended-velocity words of body i (schedWordOffset + 1 + 3 i ..)
+  __device__ __forceinline__ float* susWords(int i) const { return gst + (size_t)(schedWordOffset(S->nb, S->nj, S->np) + 1 + 3 * i) * gN; }
 
   // ------------------------------------------------------------------------------------------------
   // b2Island::Solve for the island {bodies in ibmask, contacts ic[0..nic), joints ij[0..nij)}
@@ -1503,7 +1533,8 @@ struct Env {
     static_assert(!kRegCtLds || RegI::kCtLdsWords >= 64 * 17, "frame rows must fit the contact block");
     return reinterpret_cast<uint32_t*>(ctLdsBase());
   }
-  __device__ __forceinline__ void islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
+  template <bool RESUME = false>   // see islandSolve
+  __device__ __forceinline__ bool islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio, int seed = 0, bool mayYield = false) {
 #ifdef BLCD_PROF_SOLVE
     const unsigned long long psE_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1571,9 +1602,30 @@ struct Env {
 #pragma unroll
     for (int k = 0; k < kRegC; ++k)
       if (k < nic) R.initContact(k, R.ct[k], mans[k]);
+    if constexpr (RESUME && kCanYield) {
+      // the sweeps' own state as it was at suspension: island velocities, accumulated impulses (stored raw in the manifolds)
 #pragma unroll
-    for (int k = 0; k < kRegC; ++k)
-      if (k < nic) R.warmStartContact(k, R.ct[k]);
+      for (int i = 0; i < NB; ++i) {
+        if (i < nb && ((ibmask >> i) & 1)) {
+          const float* q_ = susWords(i);
+          R.setVel(i, BodyVel{V2(q_[0], q_[(size_t)1 * gN]), q_[(size_t)2 * gN]});
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kRegC; ++k) {
+        if (k < nic) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            R.ct[k].points[j].normalImpulse = mans[k].points[j].normalImpulse;
+            R.ct[k].points[j].tangentImpulse = mans[k].points[j].tangentImpulse;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kRegC; ++k)
+        if (k < nic) R.warmStartContact(k, R.ct[k]);
+    }
     if constexpr (NJ > 0) {
 #pragma unroll
       for (int k = 0; k < NJ; ++k) {
@@ -1604,11 +1656,43 @@ struct Env {
     prof[3] += ps0_ - psE_;     // staging + constraint initialisation + warm start
 #endif
 #endif
-    int sweeps = R.velocitySweeps(S->velIters, h);
+    bool yielded = false;
+    int sweeps = R.velocitySweeps(S->velIters, h, nullptr, RESUME ? kYieldSweeps : 0,
+                                  (kCanYield && !RESUME && mayYield && nij == 0) ? kYieldSweeps : 0, yieldMaxLanes, &yielded);
 #ifdef BLCD_PROF_SOLVE
     unsigned long long ps1_ = __builtin_amdgcn_s_memtime();
     prof[4] += ps1_ - ps0_;
 #endif
+    if constexpr (kCanYield) {
+      if (yielded) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          if (i < nb && ((ibmask >> i) & 1)) {
+            const BodyVel bv_ = R.getVel(i);
+            float* q_ = susWords(i);
+            q_[0] = bv_.v.x;
+            q_[(size_t)1 * gN] = bv_.v.y;
+            q_[(size_t)2 * gN] = bv_.w;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kRegC; ++k) {
+          if (k < nic) {
+            int s = ic.get(k);
+            Manifold m = mans[k];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (j < R.ct[k].pointCount) {
+                m.points[j].normalImpulse = R.ct[k].points[j].normalImpulse;
+                m.points[j].tangentImpulse = R.ct[k].points[j].tangentImpulse;
+              }
+            selSet(man, s, m);
+          }
+        }
+        velMask |= 1u << seed;
+        return true;
+      }
+    }
     // b2ContactSolver::StoreImpulses
 #pragma unroll
     for (int k = 0; k < kRegC; ++k) {
@@ -1702,6 +1786,7 @@ struct Env {
       for (int i = 0; i < NB; ++i)
         if (i < nb && ((ibmask >> i) & 1)) sleepBody(i);
     }
+    return false;
   }
 
   // b2Island::SolveTOI for the mini-island {body b + its touching wall contacts ic[0..nic)} on the staged register island:
@@ -1807,12 +1892,14 @@ struct Env {
     syncTransform(b);
   }
 
-  __device__ __forceinline__ void islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio) {
+  // RESUME: the island was suspended at sweep kYieldSweeps in an earlier pass.  Everything up to the sweeps is recomputed from
+  // the untouched world-step-start state (same inputs, same arithmetic, same values - the bias terms need the pre-solve
+  // velocities, which is why those stay in place), then the sweeps' own state - island velocities and accumulated impulses - is
+  // put back and the loop continues at sweep kYieldSweeps.  Returns true when the island suspends (never when RESUME).
+  template <bool RESUME = false>
+  __device__ __forceinline__ bool islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio, int seed = 0, bool mayYield = false) {
     if constexpr (kUseReg) {
-      if (nic <= kRegC) {
-        islandSolveReg(ibmask, nic, nij, h, dtRatio);
-        return;
-      }
+      if (nic <= kRegC) return islandSolveReg<RESUME>(ibmask, nic, nij, h, dtRatio, seed, mayYield);
     }
     const int nb = S->nb;
     Vec2 gravity = S->gravity;
@@ -1834,9 +1921,44 @@ struct Env {
     }
     csInit(nic, true, dtRatio);
     csInitVelocityConstraints(nic);
-    csWarmStart(nic);
+    if constexpr (RESUME && kCanYield) {
+      for (int i = 0; i < NB; ++i) {
+        if (i >= nb) break;
+        if (!((ibmask >> i) & 1)) continue;
+        const float* q_ = susWords(i);
+        pv.set(i, V2(q_[0], q_[(size_t)1 * gN]));
+        pw.set(i, q_[(size_t)2 * gN]);
+      }
+#pragma unroll kU
+      for (int k = 0; k < kMaxC; ++k) {
+        if (k >= nic) break;
+        const Manifold m = selGet(man, vc[k].slot);
+#pragma unroll
+        for (int j = 0; j < kMP; ++j) {
+          vc[k].points[j].normalImpulse = m.points[j].normalImpulse;     // stored raw at suspension (no dtRatio)
+          vc[k].points[j].tangentImpulse = m.points[j].tangentImpulse;
+        }
+      }
+    } else {
+      csWarmStart(nic);
+    }
     for (int k = 0; k < nij; ++k) jointInit(ij[k], true, dtRatio);
-    velocitySweeps(ibmask, nic, nij, h);
+    if (velocitySweeps(ibmask, nic, nij, h, RESUME ? kYieldSweeps : 0, kCanYield && !RESUME && mayYield && nij == 0)) {
+      if constexpr (kCanYield) {
+        for (int i = 0; i < NB; ++i) {
+          if (i >= nb) break;
+          if (!((ibmask >> i) & 1)) continue;
+          float* q_ = susWords(i);
+          const Vec2 pvi_ = pv.get(i);
+          q_[0] = pvi_.x;
+          q_[(size_t)1 * gN] = pvi_.y;
+          q_[(size_t)2 * gN] = pw.get(i);
+        }
+        csStoreImpulses(nic);
+        velMask |= 1u << seed;
+      }
+      return true;
+    }
     csStoreImpulses(nic);
     integratePositions(ibmask, h);
     bool positionSolved = false;
@@ -1883,6 +2005,7 @@ struct Env {
         if ((ibmask >> i) & 1) sleepBody(i);
       }
     }
+    return false;
   }
 
   // island discovery of b2World::Solve from one seed body: depth-first over contact edges (world contact-list order filtered
@@ -1933,12 +2056,16 @@ struct Env {
     }
   }
 
-  // b2World::Solve
-  __device__ __forceinline__ void solve(float h, float dtRatio) {
+  // b2World::Solve.  Returns true when an island suspended in its velocity sweeps (joint-free classes, fused rollouts): the rest of
+  // the world step - that island's integration / position solve, SynchronizeFixtures of every islanded body, FindNewContacts,
+  // SolveTOI - is then owed, and solve<true> pays it in a later pass: it re-discovers the suspended islands from their seeds
+  // (velMask; same seed, same contact list, same flags => same DFS order), resumes them, and runs the tail.
+  template <bool RESUME = false>
+  __device__ __forceinline__ bool solve(float h, float dtRatio, bool mayYield = false) {
     if constexpr (NB == 1) {
       // single dynamic body: the only possible island is {body 0} with its touching contacts in contact-list order
       for (int k = 0; k < nc; ++k) pflags.clearBits(wl.get(k), PF_ISLAND);
-      if (awakeDyn(0)) {
+      if (RESUME || awakeDyn(0)) {
         int nic = 0;
         for (int k = 0; k < nc; ++k) {
           int s = wl.get(k);
@@ -1951,14 +2078,19 @@ struct Env {
           ic.set(nic++, s);
           pflags.set(s, fl | PF_ISLAND);
         }
-        islandSolve(1u, nic, 0, h, dtRatio);
+        if (islandSolve<RESUME>(1u, nic, 0, h, dtRatio, 0, mayYield)) {
+          islandedMask = 1u;
+          return true;
+        }
         synchronizeFixtures(0);
       }
+      velMask = 0;
       findNewContacts(false);
-      return;
+      return false;
     }
     const int nb = S->nb;
     uint32_t bodyIsland = 0, jointIsland = 0;
+    bool anyYield = false;
     for (int k = 0; k < nc; ++k) pflags.clearBits(wl.get(k), PF_ISLAND);
     if constexpr (NJ > 0) {
       // Islands are disjoint, so the ORDER in which they are solved changes nothing - but in a wave it decides whether the
@@ -1993,6 +2125,18 @@ struct Env {
         }
       }
       bodyIsland = allBodies;
+    } else if constexpr (RESUME) {
+      uint32_t seeds = velMask;
+      velMask = 0;
+      while (seeds) {
+        const int seed = 31 - __clz((int)seeds);
+        seeds &= ~(1u << seed);
+        uint32_t ibmask = 0;
+        int nic = 0, nij = 0;
+        islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
+        islandSolve<true>(ibmask, nic, nij, h, dtRatio, seed, false);
+      }
+      bodyIsland = islandedMask;
     } else {
       for (int seed = NB - 1; seed >= 0; --seed) {
         if (seed >= nb) continue;
@@ -2001,8 +2145,12 @@ struct Env {
         uint32_t ibmask = 0;
         int nic = 0, nij = 0;
         islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
-        islandSolve(ibmask, nic, nij, h, dtRatio);
+        anyYield = islandSolve(ibmask, nic, nij, h, dtRatio, seed, mayYield) || anyYield;
       }
+    }
+    if (anyYield) {
+      islandedMask = bodyIsland;
+      return true;
     }
 #ifdef BLCD_PROF_SOLVE2
     const unsigned long long psS_ = __builtin_amdgcn_s_memtime();
@@ -2015,6 +2163,7 @@ struct Env {
 #ifdef BLCD_PROF_SOLVE2
     prof[3] += __builtin_amdgcn_s_memtime() - psS_;   // SynchronizeFixtures + FindNewContacts
 #endif
+    return false;
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -2353,7 +2502,17 @@ struct Env {
   }
 
   // b2World::Step
-  __device__ __forceinline__ void worldStep() {
+  // the owed part of a world step that was suspended in solve() (see there)
+  __device__ __forceinline__ void worldStepResume() {
+    const float dt = S->dt;
+    const float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
+    solve<true>(dt, inv_dt0 * dt, false);
+    solveTOI(dt);
+    inv_dt0 = inv_dt;
+  }
+
+  // returns true when the environment suspended (mayYield only; the caller resumes it with worldStepResume in a later pass)
+  __device__ __forceinline__ bool worldStep(bool mayYield = false) {
     if (wflags & WF_NEWFIXTURE) {
       findNewContacts(true);
       wflags &= ~WF_NEWFIXTURE;
@@ -2371,7 +2530,9 @@ struct Env {
     unsigned long long c0_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
     if (!(skip & 1)) collide();
     unsigned long long c1_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
-    if (!(skip & 2)) solve(dt, dtRatio);
+    if (!(skip & 2)) {
+      if (solve(dt, dtRatio, mayYield)) return true;
+    }
     unsigned long long c2_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
     if (!(skip & 4)) solveTOI(dt);
     if (profOn) {
@@ -2383,6 +2544,7 @@ struct Env {
       prof[2] += c3_ - c2_;
     }
     inv_dt0 = inv_dt;
+    return false;
   }
 
   // action -> joint.motorSpeed (boxLCD/utils.py:117 mapto, world_env.py:441); b2RevoluteJoint::SetMotorSpeed wakes both bodies

@@ -349,3 +349,35 @@ def test_rebin_and_cohort_knobs_on_small_batches_change_nothing(monkeypatch, n):
     assert (res[0][0] == b[0]).all() and (res[0][1] == b[1]).all()
     for x, y in zip(res[0][2], b[2]):
       assert (x == y).all()
+
+
+@pytest.mark.parametrize('name,n', [('Dropbox', 5000), ('Object2', 5000), ('Object3', 3000), ('Bounce2', 3000)])
+def test_suspending_straggler_environments_changes_nothing(monkeypatch, name, n):
+  """Environment-level scheduling of fused chunks: a lane whose joint-free island has not converged after 24 velocity sweeps may
+  suspend its environment; a later pass of the same chunk resumes it at that sweep.  Placement in time only: frames,
+  observations and the full state equal the single-pass run, whatever the policy (never / default / always suspend), and
+  equal the oracle on a sample."""
+  T = 60
+  env, poses, sel = parity.make_batch(name, n, 21)
+  d = env.scene.desc
+  res = []
+  for knobs in ({'BLCD_YIELD_PASSES': '1'}, {}, {'BLCD_YIELD_PASSES': '5', 'BLCD_YIELD_LANES': '64'}, {'BLCD_YIELD_PASSES': '2', 'BLCD_YIELD_LANES': '8'}):
+    for k in ('BLCD_YIELD_PASSES', 'BLCD_YIELD_LANES'):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in knobs.items():
+      monkeypatch.setenv(k, v)
+    h = Handle(d, n, 0)
+    h.reset(None, poses, sel)
+    lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+    obs = np.zeros((T, n, d.n_obs), np.float32)
+    h.rollout(None, T, lcd, obs)
+    res.append((lcd, obs, [x.copy() for x in h.debug_dump()]))
+    assert not h.faults().any()
+    h.close()
+  for b in res[1:]:
+    assert (res[0][0] == b[0]).all() and (res[0][1] == b[1]).all()
+    for x, y in zip(res[0][2], b[2]):
+      assert (x == y).all()
+  idx = np.random.RandomState(2).choice(n, 64, replace=False)
+  _, _, olcd, ost = pyb2o.rollout(d, poses[idx], sel[idx], None, T, threads=8)
+  assert (ost == res[1][2][0][idx]).all() and (olcd == res[1][0][-1][idx]).all()
