@@ -37,6 +37,7 @@ SYMBOLS = {
     'blcd_sync': (C.c_int, [C.c_void_p]),
     'blcd_stream': (C.c_void_p, [C.c_void_p]),
     'blcd_last_kernel_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    'blcd_sched_stats': (C.c_int, [C.c_void_p, C.c_void_p]),
     'blcd_debug_wave_times': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_debug_world_step': (C.c_int, [C.c_void_p, C.c_int32]),
     'blcd_debug_set_motor_speeds': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -270,6 +271,13 @@ class Handle:
     ms, n = C.c_float(0), C.c_int32(0)
     _check(self.lib.blcd_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
     return ms.value, n.value
+
+  def sched_stats(self):
+    """counters of the environment-level scheduler since the last call (include/boxlcd.h blcd_sched_stats)"""
+    out = np.zeros(8, np.uint64)
+    _check(self.lib.blcd_sched_stats(self._h, _ptr(out)))
+    return dict(first_live=int(out[0]), first_suspended=int(out[1]), first_waves=int(out[2]), passes=int(out[3]),
+                later_live=int(out[4]), later_suspended=int(out[5]), later_waves=int(out[6]), max_lanes=int(out[7]))
 
   def debug_wave_times(self):
     out = np.zeros((self.n, 9), np.uint64)

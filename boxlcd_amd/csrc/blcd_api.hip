@@ -226,11 +226,21 @@ __global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restr
 // flight with the solver's own semi-implicit Euler step (no damping, bounding circle); it only decides placement, never
 // results.  Keys: 0..31 = impact predicted in that many world steps, 32 = none within 32 steps, 33 = resting on a wall,
 // 40..46 = generic work classes (heaviest first), 47 = asleep.
-constexpr int kBins = 48;
+constexpr int kBins = 49;   // + bin 0 (ahead of everything): environments suspended in the current fused chunk
 constexpr int kPredictSteps = 32;
 constexpr int kRebinBlock = 256;
 
+__device__ inline int work_class1(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode);
 __device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode) {
+  // suspended environments first and together: the resuming pass of the chunk then runs them in dense waves
+  const uint32_t prog = __float_as_uint(st[(size_t)schedWordOffset(S->nb, S->nj, S->np) * N + slot]);
+  if ((prog >> 10) & 0x7fu) return 0;
+  if (mode < 0) return 1;       // batches that are not sorted by work class: only the suspended ones move (stable sort)
+  return 1 + work_class1(S, st, N, slot, mode);
+}
+__device__ inline int work_class1(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode) {
+  constexpr int kAll = kBins;          // the bins below this function's own key space: 1 + (0 .. kAll - 2)
+  constexpr int kBins = kAll - 1;
   const int nb = S->nb, nj = S->nj, np = S->np;
   bool anyAwake = false;
   for (int i = 0; i < nb; ++i) anyAwake = anyAwake || st[(size_t)(i * kBodyFields + 12) * N + slot] != 0.0f;
@@ -581,6 +591,7 @@ struct blcd_handle_s {
   // staging
   void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
   int* dFaultAny = nullptr;  // device flag raised by step_kernel when an environment is faulted
+  unsigned long long* dSchedStats = nullptr;   // blcd_sched_stats
   uint8_t* dLut = nullptr;   // Pillow's ellipse span table for blcd_render_poses_ex (uploaded on first use)
   int lutAmax = -1;
   int* dErr = nullptr;
@@ -692,7 +703,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
     if (pass == 0) HIPCHK(hipEventRecord(e0, stream));
   }
   StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
-             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0};
+             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0, h->dSchedStats};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \
@@ -721,7 +732,9 @@ static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* 
 }
 
 // stable counting sort of slots by work class, within each cohort and on that cohort's stream; swaps the state buffers
-static int launch_rebin(blcd_handle h) {
+// midChunk: between the passes of a fused chunk (suspended environments to the front; the rest keeps its work-class order, or - in
+// batches that are not sorted by work class at all - its place)
+static int launch_rebin(blcd_handle h, bool midChunk = false) {
   const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;   // room for every cohort's block counts (rounding)
   for (int c = 0; c < h->nCohorts; ++c) {
     const int lo = h->cohortLo[c], n = h->cohortLo[c + 1] - lo;
@@ -730,7 +743,7 @@ static int launch_rebin(blcd_handle h) {
     int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
     int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
     hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->dScene, h->st + lo, h->N, n, h->keys + lo, counts,
-                       h->binMode);
+                       midChunk && h->rebinEvery <= 0 ? -1 : h->binMode);
     hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, offsets, nBlocks * kBins);
     hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->st + lo, h->st2 + lo, h->N, n, lo, (int)h->words,
                        h->keys + lo, offsets, h->eid + lo, h->eid2 + lo, h->slotOf);
@@ -738,7 +751,7 @@ static int launch_rebin(blcd_handle h) {
   HIPCHK(hipGetLastError());
   std::swap(h->st, h->st2);
   std::swap(h->eid, h->eid2);
-  h->stepsSinceRebin = 0;
+  if (!midChunk || h->rebinEvery > 0) h->stepsSinceRebin = 0;
   return BLCD_OK;
 }
 // everything outside the fused rollout runs on the handle's stream: let it see cohort 1's re-bin
@@ -918,6 +931,8 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   { int rcS = acquire_stream(device, &h->stream); if (rcS) return rcS; }
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipMalloc((void**)&h->dFaultAny, sizeof(int)));
+  HIPCHK(hipMalloc((void**)&h->dSchedStats, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(h->dSchedStats, 0, 8 * sizeof(unsigned long long), h->stream));
   HIPCHK(hipMemsetAsync(h->dFaultAny, 0, sizeof(int), h->stream));
   HIPCHK(hipEventCreate(&h->ev1));
   HIPCHK(hipMalloc((void**)&h->dScene, sizeof(DevScene)));
@@ -968,8 +983,8 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   }
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
   if (h->hostScene.nj == 0 && h->hostScene.nb <= 7 && h->hostScene.velIters > kYieldSweeps) {
-    h->yieldPasses = 3;
-    h->yieldMaxLanes = 24;
+    h->yieldPasses = 2;
+    h->yieldMaxLanes = 32;
     if (const char* ev = getenv("BLCD_YIELD_PASSES")) {
       int q = atoi(ev);
       h->yieldPasses = q < 1 ? 1 : (q > 8 ? 8 : q);
@@ -1020,6 +1035,7 @@ int blcd_destroy(blcd_handle h) {
     if (h->evJoin[c]) (void)hipEventDestroy(h->evJoin[c]);
   }
   if (h->dFaultAny) (void)hipFree(h->dFaultAny);
+  if (h->dSchedStats) (void)hipFree(h->dSchedStats);
   if (h->dLut) (void)hipFree(h->dLut);
   if (h->dErr) (void)hipFree(h->dErr);
   if (h->st) (void)hipFree(h->st);
@@ -1159,11 +1175,13 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
         int c = T - t < chunk ? T - t : chunk;
         const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
         if ((rc = rebin_if_due(h))) return rc;
-        for (int pass = 0; pass < h->yieldPasses; ++pass)
+        for (int pass = 0; pass < h->yieldPasses; ++pass) {
+          if (pass > 0 && (rc = launch_rebin(h, true))) return rc;      // suspended environments to the front, in dense waves
           for (int k = 0; k < h->nCohorts; ++k)
             if ((rc = launch_step(h, a, c, 0, 0, nullptr, nullptr, (long long)h->N * nact, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr,
                                   dObs ? (float*)dObs + obsStep * t : nullptr, k, pass, h->yieldPasses)))
               return rc;
+        }
         h->stepsSinceRebin += c;
         ++nLaunch;
       }
@@ -1179,10 +1197,12 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
       int c = T - t < chunk ? T - t : chunk;
       const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
       if ((rc = rebin_if_due(h))) return rc;
-      for (int pass = 0; pass < h->yieldPasses; ++pass)
+      for (int pass = 0; pass < h->yieldPasses; ++pass) {
+        if (pass > 0 && (rc = launch_rebin(h, true))) return rc;
         if ((rc = launch_step(h, a, c, 0, 0, h->evPool[2 * nLaunch], h->evPool[2 * nLaunch + 1], (long long)h->N * nact,
                               dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr, dObs ? (float*)dObs + obsStep * t : nullptr, -1, pass, h->yieldPasses)))
           return rc;
+      }
       h->stepsSinceRebin += c;
       ++nLaunch;
     }
@@ -1509,6 +1529,19 @@ int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_last_kernel_ms: bad handle");
   if (ms) *ms = h->lastMs;
   if (launches) *launches = h->lastLaunches;
+  return BLCD_OK;
+}
+
+int blcd_sched_stats(blcd_handle h, uint64_t* out8) {
+  if (!h || !out8) return fail(BLCD_ERR_INVALID, "blcd_sched_stats: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = join_cohort_stream(h))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(out8, h->dSchedStats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(h->dSchedStats, 0, 8 * sizeof(uint64_t)));
+  out8[3] = (uint64_t)h->yieldPasses;
+  out8[7] = (uint64_t)h->yieldMaxLanes;
   return BLCD_OK;
 }
 

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
-                                                      int pass, int yieldMaxLanes) {
+                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats) {
   uint32_t* const ldsRows = Env<NB, NJ, NP, SH>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
@@ -135,6 +135,15 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
       if (emitNow && ++t >= nEnvSteps) live = false;
     }
     *progWord = __uint_as_float((uint32_t)t | ((uint32_t)sub << 8) | (env.velMask << 10) | (env.islandedMask << 17));
+    if (schedStats && EnvT::kCanYield) {   // per pass class (first / later): lanes that entered live, lanes that left suspended, waves
+      const unsigned long long in_ = __ballot(1), sus_ = __ballot(env.velMask != 0), lv_ = __ballot((int)(prog & 0xffu) < nEnvSteps);
+      if ((int)threadIdx.x == __ffsll((long long)in_) - 1) {
+        unsigned long long* o = schedStats + (pass > 0 ? 4 : 0);
+        atomicAdd(o, (unsigned long long)__popcll(lv_));
+        atomicAdd(o + 1, (unsigned long long)__popcll(sus_));
+        atomicAdd(o + 2, 1ull);
+      }
+    }
   } else {
     if (setMotors) env.setMotorSpeeds(actions, N, e);
     for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
@@ -196,7 +205,7 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes);
+                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {
   hipLaunchKernelGGL((set_poses_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(64), 0, stream, A.S, A.st, A.N, A.slotOf, A.idxs, A.n,

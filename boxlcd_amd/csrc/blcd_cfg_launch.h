@@ -28,6 +28,7 @@ struct StepArgs {
   int* faultAny;   // set to 1 by any lane whose environment carries a fault flag after the launch
   int pass;           // fused chunks are stepped in passes: 0 starts the chunk, > 0 resumes it (progress word of every slot)
   int yieldMaxLanes;  // > 0: a lane may suspend its environment when at most this many lanes of its wave still sweep (never in the last pass)
+  unsigned long long* schedStats;   // 8 counters (see blcd_sched_stats) or null
 };
 struct SetPosesArgs {
   const DevScene* S;

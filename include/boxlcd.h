@@ -214,6 +214,11 @@ int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches);
 #define BLCD_BODY_STATE_FLOATS 12 /* cx cy a vx vy w sleepTime awake fat.lo.x fat.lo.y fat.hi.x fat.hi.y */
 #define BLCD_JOINT_STATE_FLOATS 5 /* impulse.x impulse.y impulse.z motorImpulse limitState */
 #define BLCD_PAIR_STATE_FLOATS 18 /* exists touching type pointCount ln.xy lp.xy {p.xy ni ti}x2 id0 id1 */
+/* Environment-level scheduling of fused chunks (joint-free scene classes; no reference counterpart - it only decides WHEN an
+ * environment's world step runs, never its result): counters since the last call, then reset.
+ * out8 = { first passes: lanes entered live, lanes that left suspended, waves, passes per chunk;
+ *          later passes: lanes entered live, lanes that left suspended, waves, lane threshold }. */
+int blcd_sched_stats(blcd_handle h, uint64_t* out8);
 int blcd_debug_wave_times(blcd_handle h, uint64_t* out, int32_t cap);      /* per-wave ticks (100 MHz) of the last step launch; needs BLCD_WAVETIMES=1 */
 int blcd_debug_world_step(blcd_handle h, int32_t n_world_steps);           /* n x b2World::Step only */
 int blcd_debug_set_motor_speeds(blcd_handle h, const float* actions);       /* the action half of step() only */

@@ -27,7 +27,8 @@ if len(sys.argv) > 1 and sys.argv[1] == '--one':
 else:
   name, N = sys.argv[1], sys.argv[2]
   T = sys.argv[3] if len(sys.argv) > 3 else '200'
-  for passes, lanes, chunk in (('1', None, None), (None, None, None), ('2', '24', None), ('3', '12', None), ('3', '40', None), ('4', '24', None), ('4', '64', None), ('3', '24', '10'), ('5', '32', '40')):
+  grid = [('1', None, None)] + [('2', l, c) for c in ('1', '2', '3', '5', '10', '20') for l in ('32',)] + [('2', '16', '3'), ('2', '64', '3'), ('2', '48', '5'), ('3', '32', '5')]
+  for passes, lanes, chunk in grid:
     env = dict(os.environ)
     if passes: env['BLCD_YIELD_PASSES'] = passes
     if lanes: env['BLCD_YIELD_LANES'] = lanes
