@@ -7,8 +7,11 @@ One bench "step" = `--rollouts-per-step` (default 20) such rollouts = 4 000 env-
 times ~5 s of GPU work.  Inputs (initial poses, action tape) are resident in HBM before the timed region.
 
 Weak scaling (`--gpus N`, one process per GPU, launched by torchrun): every rank owns `--envs` environments and steps them
-with no data-path collective; after every fused chunk (20 env-steps) the chunk's FULL result tensors `lcd[Tc, N, 16, W]`
-and `full_state[Tc, N, obs]` are all-gathered over RCCL on a side stream, overlapped with the next chunk.
+with no data-path collective - with EXACTLY the N=1 stepping path (one `blcd_rollout` per rollout, cohorts and all); the
+finished rollout's FULL result tensors `lcd[T, N, 16, W]` and `full_state[T, N, obs]` are then gathered over RCCL on a side
+stream in 20-step chunks while the next rollout steps into the other output buffer.  `--gather all`
+(default; north_star's all-gather) or `--gather consumer` (only rank 0 receives).  The N>1 line also carries
+`stepping_only`: the same rollouts without any transfer, so that a scaling curve separates kernel scaling from the gather.
 
 Prints ONE JSON line on rank 0: metric/value/unit, `roofline` (HBM; algorithmic bytes per env-step from SURVEY.md §8d x envs
 x env-steps per launch / mean step_kernel launch time from hipEvents on the handle's stream), `cpu_baseline` (the CPU oracle
@@ -28,9 +31,42 @@ sys.path.insert(0, ROOT)
 ALG_BYTES = {'Dropbox': 564, 'Bounce': 564, 'Object2': 924, 'Urchin': 1836, 'LuxoBall': 2236}
 HBM_PEAK_GBS = 8000.0                                                                            # MI355X_MICROARCH.md
 RASTER_NAMES = {0: 'pillow-9.0.x (inferred, no fixture)', 1: 'pillow-12.2 (goldens)', 2: "recordings' Pillow (default; pinned by the reference's GIF frames)"}
-# HBM bytes per step_kernel launch from the committed rocprofv3 PMC passes (separate --pmc runs) of the default workload;
-# only quoted when the run uses that workload with default knobs.
-TRAFFIC_PROFILE = 'profiles/r02b_bounce100k_pmc.json'
+# committed PMC summaries (tools/pmc_summary.py) per workload: HBM traffic and VALU figures are PROFILE-DERIVED (measured with
+# rocprofv3 --pmc on the same command on an earlier box, not in this run) and labelled so in the JSON line
+PMC_PROFILES = {('Bounce', 100000): 'profiles/r03_bounce100k_pmc.json', ('Dropbox', 100000): 'profiles/r03_dropbox100k_pmc.json',
+                ('Urchin', 50000): 'profiles/r03_urchin50k_pmc.json', ('LuxoBall', 50000): 'profiles/r03_luxoball50k_pmc.json',
+                ('Object2', 200000): 'profiles/r03_object2_200k_pmc.json'}
+PMC_FALLBACK = {('Bounce', 100000): 'profiles/r02b_bounce100k_pmc.json', ('Dropbox', 100000): 'profiles/r02b_dropbox100k_pmc.json',
+                ('Urchin', 50000): 'profiles/r02b_urchin50k_pmc.json', ('LuxoBall', 50000): 'profiles/r02b_luxoball50k_pmc.json'}
+
+
+def pmc_blocks(env_name, n_envs, dispatches_per_chunk=1):
+  """(traffic bytes per launch or None, traffic source, valu block or None) from the committed PMC summary of this workload."""
+  for table in (PMC_PROFILES, PMC_FALLBACK):
+    path = table.get((env_name, n_envs))
+    if not path or not os.path.exists(os.path.join(ROOT, path)):
+      continue
+    try:
+      prof = json.load(open(os.path.join(ROOT, path)))
+      k = [x for x in prof if 'step_kernel' in x][0]
+      c = prof[k]
+      traffic = src = None
+      if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        traffic = (c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0 * dispatches_per_chunk
+        src = (f'{path}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (KB -> B) per step_kernel dispatch x {dispatches_per_chunk} dispatch(es) per '
+               'chunk of the batch; profile-derived, not measured in this run')
+      valu = None
+      if 'SQ_WAVE_CYCLES' in c and 'SQ_ACTIVE_INST_VALU' in c:
+        w = c['SQ_WAVE_CYCLES']['mean']
+        valu = {'valu_busy_frac_of_wave_cycles': c['SQ_ACTIVE_INST_VALU']['mean'] / w,
+                'waiting_frac_of_wave_cycles': c['SQ_WAIT_ANY']['mean'] / w if 'SQ_WAIT_ANY' in c else None,
+                'lanes_per_valu_inst': (c['SQ_THREAD_CYCLES_VALU']['mean'] / c['SQ_ACTIVE_INST_VALU']['mean']) if 'SQ_THREAD_CYCLES_VALU' in c else None,
+                'waves_per_dispatch': c['SQ_WAVES']['mean'] if 'SQ_WAVES' in c else None, 'waves_per_simd_limit': 1,
+                'source': f'{path} (rocprofv3 --pmc SQ_* pass of the same command; profile-derived)'}
+      return traffic, src, valu
+    except Exception:
+      continue
+  return None, None, None
 
 
 def cpu_baseline(env_name, T, target_s=12.0):
@@ -89,60 +125,69 @@ class Workload:
     self.obs = torch.empty((T, N, d.n_obs), dtype=torch.float32, device=dev)
     self.kernel_ms, self.launches = 0.0, 0
     self.stream = torch.cuda.ExternalStream(self.h.stream(), device=dev)
-    self.gatherer, self.gather_done = None, {}
+    self.gatherer, self.gather_done, self.bufs, self.k = None, {}, [(self.lcd, self.obs)], 0
+    self.faulted = False
 
-  def enable_gather(self, world):
+  def enable_gather(self, world, mode, rank):
+    """Second output buffer (a rollout steps into one while the previous one's tensors travel) + the chunk gatherer."""
+    import torch
     from boxlcd_amd import dist as bdist
     c = min(self.chunk, self.T)
-    self.gatherer = bdist.ChunkGatherer(world, [self.lcd[:c], self.obs[:c]], binary=[True, False])   # mode-1 LCD frames are 0/1 bytes
+    self.bufs.append((torch.empty_like(self.lcd), torch.empty_like(self.obs)))
+    self.gatherer = bdist.ChunkGatherer(world, [self.lcd[:c], self.obs[:c]], binary=[True, False], mode=mode, rank=rank)   # mode-1 LCD frames are 0/1 bytes
 
-  def rollout(self):
+  def rollout(self, gather=True):
+    from boxlcd_amd._lib import EnvFaultError
     h = self.h
+    lcd, obs = self.bufs[self.k % len(self.bufs)]
+    self.k += 1
+    self.lcd, self.obs = lcd, obs
     h.reset(None, self.poses, self.sel)
-    if self.gatherer is None:
-      h.rollout(self.acts, self.T, self.lcd, self.obs)
-      ms, n = h.last_kernel_ms()
-      self.kernel_ms += ms
-      self.launches += n
-      return
-    for t0 in range(0, self.T, self.chunk):
-      t1 = min(self.T, t0 + self.chunk)
-      if t0 in self.gather_done:                      # the previous rollout's gather still reads this region
-        self.stream.wait_event(self.gather_done[t0])
-      h.rollout(self.acts[t0:t1], t1 - t0, self.lcd[t0:t1], self.obs[t0:t1])
-      ms, n = h.last_kernel_ms()
-      self.kernel_ms += ms
-      self.launches += n
-      if t1 - t0 == self.chunk:
-        self.gather_done[t0] = self.gatherer.gather([self.lcd[t0:t1], self.obs[t0:t1]], producer=self.stream)
+    if self.gatherer is not None and id(lcd) in self.gather_done:   # the gather that last read this buffer must be through
+      self.stream.wait_event(self.gather_done[id(lcd)])
+    try:
+      h.rollout(self.acts, self.T, lcd, obs)          # the SAME call at every N: one fused rollout, cohorts and all
+    except EnvFaultError:
+      self.faulted = True                              # the rollout completed; the flags are reported as `faulted_envs`
+    ms, n = h.last_kernel_ms()
+    self.kernel_ms += ms
+    self.launches += n
+    if self.gatherer is not None and gather:
+      for t0 in range(0, self.T - self.chunk + 1, self.chunk):
+        t1 = t0 + self.chunk
+        self.gather_done[id(lcd)] = self.gatherer.gather([lcd[t0:t1], obs[t0:t1]], producer=self.stream)
 
   def roofline(self, rollouts):
     avg_launch_s = (self.kernel_ms / max(self.launches, 1)) / 1e3
     steps_per_launch = self.T * rollouts / max(self.launches, 1)     # one launch advances N envs by this many env-steps
     bpe = ALG_BYTES.get(self.name, 0)
     achieved = bpe * self.N * steps_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    cohorts = self.d.n_joints == 0 and self.N > 65536 and os.environ.get('BLCD_COHORTS', '2') != '1'
+    traffic, tsrc, valu = pmc_blocks(self.name, self.N, 2 if cohorts and os.environ.get('BLCD_COHORTS', '2') == '2' else 1)
+    if any(k.startswith('BLCD_') for k in os.environ) or self.T != 200:
+      traffic = tsrc = valu = None                     # the committed profiles describe the default knobs only
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None, 'kernel': 'step_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
+            'traffic': traffic, 'traffic_source': tsrc, 'valu': valu, 'kernel': 'step_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
             'env_steps_per_env_per_launch': steps_per_launch, 'alg_bytes_per_env_step': bpe,
             'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'
                     + ('; this batch is stepped as two cohorts on two streams: a "launch" here is one chunk of the WHOLE batch (two '
                        'concurrent step_kernel launches), avg_launch_ms = the overlapped sequence (re-bin kernels included) / chunks'
-                       if self.d.n_joints == 0 and self.N > 65536 and os.environ.get('BLCD_COHORTS', '2') != '1' else '')}
+                       if cohorts else '')}
 
   def close(self):
     self.h.close()
 
 
-def time_rollouts(w, rollouts, warmup, bdist, torch):
+def time_rollouts(w, rollouts, warmup, bdist, torch, gather=True):
   for _ in range(warmup):
-    w.rollout()
+    w.rollout(gather)
   if w.gatherer is not None:
     w.gatherer.finish()
   w.kernel_ms, w.launches = 0.0, 0
   bdist.barrier(); torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(rollouts):
-    w.rollout()
+    w.rollout(gather)
   if w.gatherer is not None:
     w.gatherer.finish()
   torch.cuda.synchronize(); bdist.barrier()
@@ -160,6 +205,7 @@ def main():
   ap.add_argument('--rollout-len', type=int, default=200)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-configs', action='store_true', help='skip the extra single-GPU workloads of the `configs` block')
+  ap.add_argument('--gather', choices=['all', 'consumer'], default='all', help='N>1: all-gather to every rank, or gather to rank 0 only')
   args = ap.parse_args()
 
   world_env = int(os.environ.get('WORLD_SIZE', '1'))
@@ -189,37 +235,27 @@ def main():
     raise RuntimeError('bench.py needs a GPU: boxlcd_amd has no CPU path')
   torch.cuda.set_device(local)
   dev = torch.device('cuda', local)
-  if world > 1:
-    # the N>1 path feeds 20-step calls to overlap the gather: each call ends with a sync, so cohorts buy nothing there, and the
-    # gather's side stream + RCCL's own already occupy hardware queues (a fourth compute stream halves throughput)
-    os.environ.setdefault('BLCD_COHORTS', '1')
   N, T = args.envs, args.rollout_len
   overrides = {k: v for k, v in os.environ.items() if k.startswith('BLCD_') or k.startswith('BOXLCD_')}
 
   w = Workload(args.env, N, T, local, dev, seed=1000 + rank)
   d = w.d
   if world > 1:
-    w.enable_gather(world)
+    w.enable_gather(world, args.gather, rank)
   torch.cuda.synchronize()
   rollouts = args.steps * args.rollouts_per_step
   dt = time_rollouts(w, rollouts, args.warmup * args.rollouts_per_step, bdist, torch)
+  stepping_only = None
+  if world > 1:   # the same rollouts with no transfer at all (outside the timed region above): kernel scaling by itself
+    r2 = max(1, min(rollouts, 2 * args.rollouts_per_step))
+    stepping_only = {'value': float(r2) * T * N * world / time_rollouts(w, r2, 0, bdist, torch, gather=False), 'unit': 'env-steps/s',
+                     'rollouts': r2, 'note': 'identical stepping path, gather skipped; max over ranks, barrier + synchronize on both sides'}
 
   faults = int((w.h.faults() != 0).sum())
   awake_frac = float(w.h.get_poses()[:, :, 3].mean())
   if rank == 0:
     total_env_steps = float(rollouts) * T * N * world
     roof = w.roofline(rollouts)
-    default_knobs = args.env == 'Bounce' and N == 100000 and T == 200 and not overrides
-    if default_knobs:
-      try:
-        prof = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
-        k = [x for x in prof if 'step_kernel' in x][0]
-        per_chunk = 1 if os.environ.get('BLCD_COHORTS', '2') == '1' else 2     # two cohort kernels make one chunk of the batch
-        roof['traffic'] = (prof[k]['FETCH_SIZE']['mean'] + prof[k]['WRITE_SIZE']['mean']) * 1024.0 * per_chunk
-        roof['traffic_source'] = (f'{TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (KB -> B) per step_kernel dispatch of this same '
-                                  f'command x {per_chunk} dispatches per chunk of the batch; profile-derived, not measured in this run')
-      except Exception:
-        roof['traffic'] = None
     out = {
         'metric': 'env_steps_per_sec', 'value': total_env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
@@ -227,11 +263,13 @@ def main():
         'config': {'workload': f'envs.{args.env}() {d.lcd_h}x{d.lcd_w}, {N} envs/GPU, one step = {args.rollouts_per_step} rollouts of {T} env-steps '
                                'from reset, U(-1,1) actions, obs + LCD rendered every env-step', 'envs_per_gpu': N, 'rollout_len': T,
                    'rollouts_per_step': args.rollouts_per_step, 'parallelism': f'env-sharded x{world}',
-                   'collective': None if world == 1 else f'all-gather of every chunk\'s lcd[{w.chunk},{N},{d.lcd_h},{d.lcd_w}] u8 (1 bit per pixel on the wire, delivered as u8) + full_state[{w.chunk},{N},{d.n_obs}] f32 on a side stream',
+                   'collective': None if world == 1 else ('all-gather' if args.gather == 'all' else 'gather to rank 0') + f' of every chunk\'s lcd[{w.chunk},{N},{d.lcd_h},{d.lcd_w}] u8 (1 bit per pixel on the wire, delivered as u8) + full_state[{w.chunk},{N},{d.n_obs}] f32 on a side stream, overlapped with the next rollout',
                    'raster_variant': RASTER_NAMES.get(w.venv.raster_variant, str(w.venv.raster_variant)), 'overrides': overrides,
                    'faulted_envs': faults, 'awake_fraction_at_end': awake_frac},
         'roofline': roof,
     }
+    if stepping_only is not None:
+      out['stepping_only'] = stepping_only
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args.env, T)
       idx = np.random.RandomState(0).choice(N, min(N, 1024), replace=False)

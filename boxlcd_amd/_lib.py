@@ -21,6 +21,7 @@ SYMBOLS = {
     'blcd_set_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'blcd_rollout_bits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_goal_set': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_goal_seed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_goal_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -176,6 +177,13 @@ class Handle:
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (T, self.n, self.n_act), actions.shape
     _check(self.lib.blcd_rollout(self._h, _ptr(actions), int(T), _ptr(lcd_out), _ptr(obs_out)))
+
+  def rollout_bits(self, actions, T, lcd_bits_out=None, obs_out=None):
+    """rollout() with frames at one bit per pixel: lcd_bits_out uint8 [T, n, lcd_h, lcd_w // 8], numpy bitorder='little'"""
+    if actions is not None and not hasattr(actions, 'data_ptr'):
+      actions = np.ascontiguousarray(actions, dtype=np.float32)
+      assert actions.shape == (T, self.n, self.n_act), actions.shape
+    _check(self.lib.blcd_rollout_bits(self._h, _ptr(actions), int(T), _ptr(lcd_bits_out), _ptr(obs_out)))
 
   def goal_set(self, mode, idxs_cols, thresh, rew_scale, diff_delt, goal_full_state, goal_lcd=None, env_idxs=None):
     g = GoalDesc()

@@ -689,7 +689,7 @@ static int pick_cfg(const DevScene& S) {
 // after the last, so a "launch" of the timing code stays one chunk of the batch
 static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors,
                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, long long actStride = 0, uint8_t* lcdOut = nullptr,
-                       float* obsOut = nullptr, int cohort = -1, int pass = 0, int nPasses = 1) {
+                       float* obsOut = nullptr, int cohort = -1, int pass = 0, int nPasses = 1, int lcdBits = 0) {
   const int lanes = h->lanes;
   const int lo = cohort < 0 ? 0 : h->cohortLo[cohort];
   const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
@@ -703,7 +703,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
     if (pass == 0) HIPCHK(hipEventRecord(e0, stream));
   }
   StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
-             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0, h->dSchedStats};
+             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \
@@ -983,7 +983,10 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   }
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
   if (h->hostScene.nj == 0 && h->hostScene.nb <= 7 && h->hostScene.velIters > kYieldSweeps) {
-    h->yieldPasses = 2;
+    // measured: chunk-level passes do not pay - a suspended environment's remaining chunk is as long a critical
+    // path in the resuming pass as it was in the first - so the default is OFF; the mechanism stays (it is what the
+    // schedule-invariance test and the asynchronous scheduler build on): BLCD_YIELD_PASSES=2 BLCD_YIELD_LANES=32 turns it on
+    h->yieldPasses = 1;
     h->yieldMaxLanes = 32;
     if (const char* ev = getenv("BLCD_YIELD_PASSES")) {
       int q = atoi(ev);
@@ -1131,11 +1134,21 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
   return fault_status(h);
 }
 
+static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out, int lcdBits);
 int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out) {
+  return rollout_impl(h, actions, T, lcd_out, obs_out, 0);
+}
+int blcd_rollout_bits(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_bits_out, float* obs_out) {
+  if (h && (h->hostScene.lcdW % 8) != 0) return fail(BLCD_ERR_UNSUPPORTED, "blcd_rollout_bits: the LCD width must be a multiple of 8");
+  if (h && !((h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0))
+    return fail(BLCD_ERR_UNSUPPORTED, "blcd_rollout_bits: only the fused rollout path (16-row frames, or 32-row frames of the large class) packs frames");
+  return rollout_impl(h, actions, T, lcd_bits_out, obs_out, 1);
+}
+static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out, int lcdBits) {
   if (!h || T < 1) return fail(BLCD_ERR_INVALID, "blcd_rollout: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   const int nact = h->hostScene.nact, nobs = h->hostScene.nobs;
-  const size_t lcdStep = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW;
+  const size_t lcdStep = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW / (lcdBits ? 8 : 1);
   const size_t obsStep = (size_t)h->N * nobs;
   const void* dAct;
   void *dLcd, *dObs;
@@ -1179,7 +1192,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
           if (pass > 0 && (rc = launch_rebin(h, true))) return rc;      // suspended environments to the front, in dense waves
           for (int k = 0; k < h->nCohorts; ++k)
             if ((rc = launch_step(h, a, c, 0, 0, nullptr, nullptr, (long long)h->N * nact, dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr,
-                                  dObs ? (float*)dObs + obsStep * t : nullptr, k, pass, h->yieldPasses)))
+                                  dObs ? (float*)dObs + obsStep * t : nullptr, k, pass, h->yieldPasses, lcdBits)))
               return rc;
         }
         h->stepsSinceRebin += c;
@@ -1200,7 +1213,7 @@ int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_ou
       for (int pass = 0; pass < h->yieldPasses; ++pass) {
         if (pass > 0 && (rc = launch_rebin(h, true))) return rc;
         if ((rc = launch_step(h, a, c, 0, 0, h->evPool[2 * nLaunch], h->evPool[2 * nLaunch + 1], (long long)h->N * nact,
-                              dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr, dObs ? (float*)dObs + obsStep * t : nullptr, -1, pass, h->yieldPasses)))
+                              dLcd ? (uint8_t*)dLcd + lcdStep * t : nullptr, dObs ? (float*)dObs + obsStep * t : nullptr, -1, pass, h->yieldPasses, lcdBits)))
           return rc;
       }
       h->stepsSinceRebin += c;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
-                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats) {
+                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits) {
   uint32_t* const ldsRows = Env<NB, NJ, NP, SH>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     // Fused rollout: this wave advances its environments through all nEnvSteps on its own (no grid-wide barrier between
     // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.  Lanes progress
     // at their own pace: a lane whose environment suspends (worldStep returns true) idles until the next pass.
-    const size_t lcdRow = (size_t)S->lcdH * S->lcdW;
+    const size_t lcdRow = (size_t)S->lcdH * S->lcdW / (lcdBits ? 8 : 1);   // bytes per frame (lcdBits: one bit per pixel)
     const bool mayYield = EnvT::kCanYield && yieldMaxLanes > 0;
     bool resume = EnvT::kCanYield && env.velMask != 0;
     while (__any(live)) {
@@ -84,7 +84,19 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
           *sel = env.sel[bi];
         };
         bool ok = true;
-        if (lcdOut && S->lcdW == 16 && fullWave) {
+        if (lcdOut && lcdBits && S->lcdW == 16) {
+          // 16x16 frames at one bit per pixel: 32 B per environment, straight from the row masks (complemented: 1 = background)
+          if (emitNow) {
+            uint32_t rows[16];
+            ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (~rows[2 * j] & 0xffffu) | (~rows[2 * j + 1] << 16);
+            uint4* o = reinterpret_cast<uint4*>(lcdOut + ((size_t)t * N + e) * 32);
+            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+          }
+        } else if (lcdOut && S->lcdW == 16 && fullWave) {
           // 16x16 frames: 256 B = one dword per lane.  Writing each lane's own frame row by row makes every store touch 64
           // different cache lines; instead the emitting lanes park their 16 row masks in LDS and the WHOLE wave writes one frame
           // per store instruction (fully coalesced): frame k = the environment held by lane k, at that lane's own env-step.
@@ -127,8 +139,8 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
           uint8_t* lcdRowOut = lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr;
           bool tall = false;
           if constexpr (NB > 7) tall = S->lcdH == 32;   // 32-row LCDs (Crab, CrabCube, SpiderCube) only occur in the largest class
-          if (tall) ok = emit_env<32, uint64_t, float, false>(S, body, obsRowOut, lcdRowOut);
-          else ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowOut, lcdRowOut);
+          if (tall) ok = emit_env<32, uint64_t, float, false>(S, body, obsRowOut, lcdRowOut, nullptr, lcdBits != 0);
+          else ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowOut, lcdRowOut, nullptr, lcdBits != 0);
         }
         if (!ok) env.fault |= FAULT_ELLIPSE;
       }
@@ -205,7 +217,7 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats);
+                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {
   hipLaunchKernelGGL((set_poses_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(64), 0, stream, A.S, A.st, A.N, A.slotOf, A.idxs, A.n,

@@ -29,6 +29,7 @@ struct StepArgs {
   int pass;           // fused chunks are stepped in passes: 0 starts the chunk, > 0 resumes it (progress word of every slot)
   int yieldMaxLanes;  // > 0: a lane may suspend its environment when at most this many lanes of its wave still sweep (never in the last pass)
   unsigned long long* schedStats;   // 8 counters (see blcd_sched_stats) or null
+  int lcdBits;        // lcdOut holds frames at one bit per pixel (blcd_rollout_bits)
 };
 struct SetPosesArgs {
   const DevScene* S;

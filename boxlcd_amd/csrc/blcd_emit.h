@@ -13,7 +13,7 @@ constexpr int kBlock = 64;  // one wave per workgroup: N/64 workgroups spread ov
 // yields transform position, body angle and shape choice of body i.  Shared by obs_kernel and the fused rollout path.
 template <int H, typename RowT, typename ObsT, bool CIRC = false, typename BodyFn>
 __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn body, ObsT* __restrict__ obsRow,
-                                         uint8_t* __restrict__ lcdRow, RowT* __restrict__ rowsOut = nullptr) {
+                                         uint8_t* __restrict__ lcdRow, RowT* __restrict__ rowsOut = nullptr, bool lcdBits = false) {
   bool ok = true;
   if (obsRow) {
     int cachedKey = -1;   // (body, angle source) whose float64 sin/cos are in cs / cc: the cos and sin entries of a body are
@@ -65,6 +65,8 @@ __device__ __forceinline__ bool emit_env(const DevScene* __restrict__ S, BodyFn 
     if (rowsOut) {   // the caller writes the frame itself (wave-coalesced, see step_kernel): rows in output order
 #pragma unroll
       for (int y = 0; y < H; ++y) rowsOut[y] = r.rows[H - 1 - y];
+    } else if (lcdBits) {
+      r.writeBits(lcdRow);
     } else {
       r.write(lcdRow);
     }

@@ -169,6 +169,16 @@ struct Raster {
     return true;
   }
 
+  // the same frame at ONE BIT per pixel: uint8 [H][W / 8], pixel x of a row = bit (x % 8) of byte x / 8 (numpy bitorder='little'),
+  // 1 = background, 0 = body, rows flipped.  This is what the raster holds anyway (the complement of its row masks).
+  __device__ void writeBits(uint8_t* __restrict__ out) const {
+    for (int r = 0; r < H; ++r) {
+      const RowT m = ~rows[H - 1 - r];
+      uint8_t* o = out + r * (W / 8);
+      for (int x0 = 0; x0 < W; x0 += 8) o[x0 / 8] = (uint8_t)((m >> x0) & 0xffu);
+    }
+  }
+
   // uint8 [H][W], 1 = background, 0 = body, rows flipped (FLIP_TOP_BOTTOM)
   __device__ void write(uint8_t* __restrict__ out) const {
     for (int r = 0; r < H; ++r) {

@@ -63,32 +63,41 @@ class ChunkGatherer:
   `producer` is the stream the chunk was written on (the handle's stream); the returned event marks the end of the gather:
   make the producer wait on it before it rewrites the source region (`producer.wait_event(ev)`)."""
 
-  def __init__(self, world, templates, nbuf=2, binary=None):
+  def __init__(self, world, templates, nbuf=2, binary=None, mode='all', rank=0):
     """`binary[i]` = True declares tensor i to hold only 0/1 bytes (LCD frames in mode '1'): it is bit-packed for the wire.
     Packing keeps bit 0 of every byte, so it is strictly opt-in - RGB frames or LCDs scaled to 255 must not be declared."""
     import torch
     self.world = world
+    # mode 'all': every rank receives every rank's chunk (all-gather, north_star's wording); 'consumer': only rank 0 does
+    # (gather to the consuming rank - what a single trainer process needs; the other ranks only send)
+    assert mode in ('all', 'consumer')
+    self.mode, self.rank = mode, rank
     self.cuda = templates[0].is_cuda
     binary = [False] * len(templates) if binary is None else list(binary)
     assert len(binary) == len(templates)
     for t, b in zip(templates, binary):
       assert not b or (t.dtype == torch.uint8 and t.numel() % 8 == 0), 'binary tensors must be uint8 with a multiple of 8 elements'
-    self.bufs = [[torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in templates] for _ in range(nbuf)]
+    recv = mode == 'all' or rank == 0
+    self.bufs = [[torch.empty((world if recv else 0,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in templates] for _ in range(nbuf)]
     self.k = 0
     self.stream = torch.cuda.Stream(device=templates[0].device) if self.cuda else None
     # packed staging for the uint8 tensors (GPU only: the kernels live in the HIP library)
     self.packed = [self.cuda and b for b in binary]
     self.pk_src = [torch.empty(t.numel() // 8, dtype=torch.uint8, device=t.device) if p else None for t, p in zip(templates, self.packed)]
-    self.pk_dst = [torch.empty(world * t.numel() // 8, dtype=torch.uint8, device=t.device) if p else None for t, p in zip(templates, self.packed)]
+    self.pk_dst = [torch.empty((world if recv else 0) * t.numel() // 8, dtype=torch.uint8, device=t.device) if p else None for t, p in zip(templates, self.packed)]
 
   def gather(self, srcs, producer=None):
     import torch
     import torch.distributed as dist
     dst = self.bufs[self.k % len(self.bufs)]
     self.k += 1
+    consumer = self.mode == 'consumer'
     if not self.cuda:                       # gloo rehearsal on CPU: synchronous
       for d, s in zip(dst, srcs):
-        dist.all_gather(list(d.unbind(0)), s.contiguous())
+        if consumer:
+          dist.gather(s.contiguous(), list(d.unbind(0)) if self.rank == 0 else None, dst=0)
+        else:
+          dist.all_gather(list(d.unbind(0)), s.contiguous())
       return None
     from . import _lib
     ready = torch.cuda.Event()
@@ -101,8 +110,14 @@ class ChunkGatherer:
         if self.packed[i]:
           assert s.data_ptr() % 8 == 0, 'bit-packed sources must be 8-byte aligned'
           _lib.pack_bits(s, self.pk_src[i], sp)
-          dist.all_gather_into_tensor(self.pk_dst[i], self.pk_src[i])
-          _lib.unpack_bits(self.pk_dst[i], d, sp)
+          if consumer:
+            dist.gather(self.pk_src[i], list(self.pk_dst[i].view(self.world, -1).unbind(0)) if self.rank == 0 else None, dst=0)
+          else:
+            dist.all_gather_into_tensor(self.pk_dst[i], self.pk_src[i])
+          if not consumer or self.rank == 0:
+            _lib.unpack_bits(self.pk_dst[i], d, sp)
+        elif consumer:
+          dist.gather(s, list(d.unbind(0)) if self.rank == 0 else None, dst=0)
         else:
           dist.all_gather_into_tensor(d.flatten(0, 1), s)   # [world*Tc, N, ...] = concatenation along dim 0 (NCCL and gloo)
       done = torch.cuda.Event()

@@ -132,6 +132,11 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps);
  * SIMD: 20 env-steps with slot re-binning in between; everything else: up to 200, sized from the previous rollout's time
  * per step; BLCD_CHUNK=<n> pins it) - results do not depend on the cut. */
 int blcd_rollout(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out);
+/* The same rollout with the frames at ONE BIT per pixel - what `lcd` is in the reference (a bool array, world_env.py:508-509)
+ * and what north_star calls the "1-bit framebuffer": lcd_bits_out uint8 [T][n_envs][lcd_h][lcd_w / 8], pixel x of a row =
+ * bit (x % 8) of byte x / 8 (numpy.unpackbits(..., bitorder='little') gives blcd_rollout's bytes), 1 = background.
+ * 8x less store traffic for the tensor that is ~94 % of a chunk's bytes.  lcd_w must be a multiple of 8 (every catalogue env). */
+int blcd_rollout_bits(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_bits_out, float* obs_out);
 
 /* Replaces WorldEnv._get_obs() (world_env.py:387-429) incl. lcd_render() (:460-512).
  * full_state: normalised [n_envs][n_obs], dtype 0 = float32 (vector-env layout, async_vector_env.py:374-378),

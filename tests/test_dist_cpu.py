@@ -31,6 +31,15 @@ def _worker(rank, world, port, n_total, q):
     gl, go = g.last()
     chunk_ok = chunk_ok and gl.shape == (w, Tc, n_eq, 16, 16) and all((gl[k] == 10 * chunk + k).all() and (go[k] == 10 * chunk + k).all() for k in range(w))
   g.finish()
+  # consumer mode: only rank 0 receives (gather to the consuming rank), the others only send
+  gc = bdist.ChunkGatherer(w, [torch.empty((Tc, n_eq, 16, 16), dtype=torch.uint8), torch.empty((Tc, n_eq, 4))], mode='consumer', rank=r)
+  gc.gather([torch.full((Tc, n_eq, 16, 16), 50 + r, dtype=torch.uint8), torch.full((Tc, n_eq, 4), float(50 + r))])
+  gl, go = gc.last()
+  if r == 0:
+    chunk_ok = chunk_ok and gl.shape == (w, Tc, n_eq, 16, 16) and all((gl[k] == 50 + k).all() and (go[k] == 50 + k).all() for k in range(w))
+  else:
+    chunk_ok = chunk_ok and gl.shape[0] == 0
+  gc.finish()
   t = bdist.max_over_ranks(1.0 + rank)
   bdist.barrier()
   ok = full_lcd.shape == (n_total, 16, 16) and (full_lcd[:, 0, 0].numpy() == np.arange(n_total)).all() and \

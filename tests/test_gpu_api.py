@@ -247,3 +247,31 @@ def test_chunk_gather_of_full_rollout_tensors_two_ranks():
   res = [q.get(timeout=240) for _ in procs]
   for p in procs: p.join(timeout=60)
   assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize('name,n', [('Bounce', 4096), ('Dropbox', 1000), ('LuxoBall', 300), ('Urchin', 257), ('Crab', 64)])
+def test_rollout_bits_unpacks_to_the_uint8_frames(name, n):
+  """blcd_rollout_bits: the row masks the raster holds, one bit per pixel (north_star's "1-bit framebuffer"; `lcd` is a bool array
+  in the reference, world_env.py:508-509).  numpy.unpackbits(bitorder='little') of it equals blcd_rollout's uint8 frames for
+  16-, 24-, 32- and 64-pixel-wide LCDs, full and ragged waves; observations and final state are those of blcd_rollout."""
+  T = 25
+  env = B.BatchedWorldEnv(name, n, seed=77)
+  poses, sel = env.sample_initial(n)
+  acts = env.sample_actions(T)
+  d = env.scene.desc
+  outs = []
+  for bits in (False, True):
+    h = Handle(d, n, 0)
+    h.reset(None, poses, sel)
+    obs = np.zeros((T, n, d.n_obs), np.float32)
+    if bits:
+      lcd = np.full((T, n, d.lcd_h, d.lcd_w // 8), 0xAA, np.uint8)
+      h.rollout_bits(acts, T, lcd, obs)
+      lcd = np.unpackbits(lcd, axis=-1, bitorder='little')
+    else:
+      lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+      h.rollout(acts, T, lcd, obs)
+    outs.append((lcd, obs, h.debug_dump()[0].copy()))
+    h.close()
+  assert outs[0][0].shape == outs[1][0].shape and (outs[0][0] == outs[1][0]).all()
+  assert (outs[0][1] == outs[1][1]).all() and (outs[0][2] == outs[1][2]).all()

@@ -355,13 +355,13 @@ def test_rebin_and_cohort_knobs_on_small_batches_change_nothing(monkeypatch, n):
 def test_suspending_straggler_environments_changes_nothing(monkeypatch, name, n):
   """Environment-level scheduling of fused chunks: a lane whose joint-free island has not converged after 24 velocity sweeps may
   suspend its environment; a later pass of the same chunk resumes it at that sweep.  Placement in time only: frames,
-  observations and the full state equal the single-pass run, whatever the policy (never / default / always suspend), and
+  observations and the full state equal the single-pass run, whatever the policy (never / at most 32 lanes / always / at most 8 lanes), and
   equal the oracle on a sample."""
   T = 60
   env, poses, sel = parity.make_batch(name, n, 21)
   d = env.scene.desc
   res = []
-  for knobs in ({'BLCD_YIELD_PASSES': '1'}, {}, {'BLCD_YIELD_PASSES': '5', 'BLCD_YIELD_LANES': '64'}, {'BLCD_YIELD_PASSES': '2', 'BLCD_YIELD_LANES': '8'}):
+  for knobs in ({'BLCD_YIELD_PASSES': '1'}, {'BLCD_YIELD_PASSES': '2'}, {'BLCD_YIELD_PASSES': '5', 'BLCD_YIELD_LANES': '64'}, {'BLCD_YIELD_PASSES': '2', 'BLCD_YIELD_LANES': '8'}):
     for k in ('BLCD_YIELD_PASSES', 'BLCD_YIELD_LANES'):
       monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
