@@ -703,7 +703,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
     if (pass == 0) HIPCHK(hipEventRecord(e0, stream));
   }
   StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
-             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits};
+             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits, nPasses > 1 ? 1 : 0};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \

@@ -18,14 +18,14 @@
 
 namespace blcd {
 
-template <int NB, int NJ, int NP, int SH>
+template <int NB, int NJ, int NP, int SH, bool SCHED>
 __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, int nSlots,
                                                       const int* __restrict__ eid, const float* __restrict__ actions,
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
                                                       int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits) {
-  uint32_t* const ldsRows = Env<NB, NJ, NP, SH>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
+  uint32_t* const ldsRows = Env<NB, NJ, NP, SH, SCHED>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
   // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
@@ -33,7 +33,93 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   int slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
   if (slot >= nSlots) return;
   const int e = eid[slot];
-  using EnvT = Env<NB, NJ, NP, SH>;
+  using EnvT = Env<NB, NJ, NP, SH, SCHED>;
+  if constexpr (!SCHED) {
+    // ---- the plain kernel: every lane runs its environment through the whole launch in lock step ----
+    EnvT env;
+    env.load(S, st, N, slot);
+    env.profOn = waveTimes != nullptr;
+#ifdef BLCD_ABLATION
+    if (S->dbgSkip & 8) nEnvSteps = nWorldSteps = 0;
+#endif
+    if (nEnvSteps > 0) {
+      // Fused rollout: this wave advances its environments through all nEnvSteps on its own (no grid-wide barrier between
+      // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.
+      const size_t lcdRow = (size_t)S->lcdH * S->lcdW / (lcdBits ? 8 : 1);   // bytes per frame (lcdBits: one bit per pixel)
+      for (int t = 0; t < nEnvSteps; ++t) {
+        env.setMotorSpeeds(actions ? actions + (size_t)t * actStride : nullptr, N, e);
+        for (int k = 0; k < S->substeps; ++k) env.worldStep();
+        if (lcdOut || obsOut) {
+          auto body = [&](int i, Vec2* p, float* a, int* sel) {
+            const int bi = NB == 1 ? 0 : i;  // static index for single-body scenes (keeps env in registers)
+            *p = env.xfp[bi];
+            *a = env.a[bi];
+            *sel = env.sel[bi];
+          };
+          bool ok;
+          if (lcdOut && lcdBits && S->lcdW == 16) {
+            // 16x16 frames at one bit per pixel: 32 B per environment, straight from the row masks (complemented: 1 = background)
+            uint32_t rows[16];
+            ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (~rows[2 * j] & 0xffffu) | (~rows[2 * j + 1] << 16);
+            uint4* o = reinterpret_cast<uint4*>(lcdOut + ((size_t)t * N + e) * 32);
+            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+          } else if (lcdOut && S->lcdW == 16 && __ballot(1) == ~0ull) {   // full waves only: a frame needs all 64 lanes to write it
+            // 16x16 frames: 256 B = one dword per lane.  Writing each lane's own frame row by row makes every store touch 64
+            // different cache lines; instead the lanes park their 16 row masks in LDS and the wave writes one whole frame per
+            // store instruction (fully coalesced), frame k being the environment held by lane k.
+            uint32_t rows[16];
+            ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
+            const int lane = (int)threadIdx.x;
+#pragma unroll
+            for (int y = 0; y < 16; ++y) ldsRows[lane * 17 + y] = rows[y];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint8_t* frames = lcdOut + (size_t)t * N * lcdRow;
+            const int row = lane >> 2, x0 = (lane & 3) * 4;   // this lane's 4 pixels of any frame
+            for (int k = 0; k < 64; ++k) {
+              const int ek = __builtin_amdgcn_readlane(e, k);
+              const uint32_t m = ldsRows[k * 17 + row];
+              const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+              *reinterpret_cast<uint32_t*>(frames + (size_t)ek * 256 + 4 * lane) = px;
+            }
+            __builtin_amdgcn_wave_barrier();
+          } else {
+            float* obsRowOut = obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr;
+            uint8_t* lcdRowOut = lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr;
+            bool tall = false;
+            if constexpr (NB > 7) tall = S->lcdH == 32;   // 32-row LCDs (Crab, CrabCube, SpiderCube) only occur in the largest class
+            if (tall) ok = emit_env<32, uint64_t, float, false>(S, body, obsRowOut, lcdRowOut, nullptr, lcdBits != 0);
+            else ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowOut, lcdRowOut, nullptr, lcdBits != 0);
+          }
+          if (!ok) env.fault |= FAULT_ELLIPSE;
+        }
+      }
+    } else {
+      if (setMotors) env.setMotorSpeeds(actions, N, e);
+      for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
+    }
+    env.checkFault();
+    if (env.fault && faultAny) *faultAny = 1;
+    env.store(st, N, slot);
+    if (waveTimes) {
+      // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
+      unsigned long long* o = waveTimes + (size_t)blockIdx.x * 9;
+      if (threadIdx.x == 0) o[0] = __builtin_amdgcn_s_memrealtime() - t0;
+#ifdef BLCD_PROF_TOI2
+      for (int k = 0; k < 8; ++k) atomicAdd(&o[1 + k], env.prof[k]);   // wave totals (one lane records each interval)
+#else
+      for (int k = 0; k < 6; ++k) atomicMax(&o[1 + k], env.prof[k]);
+      for (int k = 6; k < 8; ++k) atomicAdd(&o[1 + k], env.prof[k]);
+#endif
+    }
+    return;
+  } else {
+  // ---- the scheduler's kernel ----
   // Progress inside a fused chunk (environment-level scheduling): a chunk is stepped in `passes`; pass 0 starts
   // every environment at env-step 0, a later pass picks each environment up where the previous one left it - finished (the lane
   // idles), or suspended in the velocity sweeps of one of its islands (the lane resumes that world step first).
@@ -174,6 +260,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     for (int k = 6; k < 8; ++k) atomicAdd(&o[1 + k], env.prof[k]);
 #endif
   }
+  }   // SCHED
 }
 
 // b2Body::SetTransform per masked body: position first, then angle (two calls, like `body.position=`; `body.angle=`),
@@ -216,7 +303,15 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 #define BLCD_NAME(p, a, b, c, d) BLCD_PASTE5(p, a, b, c, d)
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
-  hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
+  // the scheduler's kernel exists for the classes it can act on (joint-free, see Env::kCanYield) and runs only when asked for
+  if constexpr (BLCD_NJ == 0 && BLCD_NB <= 7) {
+    if (A.sched) {
+      hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, true>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
+                         A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, false>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
                      A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {

@@ -30,6 +30,7 @@ struct StepArgs {
   int yieldMaxLanes;  // > 0: a lane may suspend its environment when at most this many lanes of its wave still sweep (never in the last pass)
   unsigned long long* schedStats;   // 8 counters (see blcd_sched_stats) or null
   int lcdBits;        // lcdOut holds frames at one bit per pixel (blcd_rollout_bits)
+  int sched;          // launch the scheduler's kernel (step_kernel<..., true>): passes / suspension / resumption
 };
 struct SetPosesArgs {
   const DevScene* S;

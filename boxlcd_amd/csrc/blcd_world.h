@@ -254,7 +254,9 @@ struct BodyCol<Vec2, N, true> {
   }
 };
 
-template <int NB, int NJ, int NP, int SH = 0>
+// SCHED: the environment-level scheduler's kernels (suspend / resume).  It is a compile-time switch because the
+// tuned one-body kernels lose 8-29 % when the suspension paths are merely present (registers, loop shape).
+template <int NB, int NJ, int NP, int SH = 0, bool SCHED = false>
 struct Env {
   static constexpr bool kCirc = SH == 1;
   static constexpr int kMP = kCirc ? 1 : 2;  // manifold points a contact can have
@@ -324,7 +326,7 @@ struct Env {
   uint8_t ij[NJ > 0 ? NJ : 1];
 
   // --- environment-level scheduling (fused rollouts) ---
-  static constexpr bool kCanYield = NJ == 0 && NB <= 7;   // joint-free classes: their sweeps have an early exit that stragglers miss
+  static constexpr bool kCanYield = SCHED && NJ == 0 && NB <= 7;   // joint-free classes: their sweeps have an early exit that stragglers miss
   float* gst;            // this slot's column of the state array (word f at gst[f * gN]): suspended velocities go straight there
   int gN;
   uint32_t velMask;      // seeds of the islands suspended in their velocity sweeps
@@ -336,8 +338,10 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void load(const DevScene* scene, const float* __restrict__ st, int N, int e) {
     S = scene;
-    gst = const_cast<float*>(st) + e;
-    gN = N;
+    if constexpr (SCHED) {
+      gst = const_cast<float*>(st) + e;
+      gN = N;
+    }
     velMask = 0;
     islandedMask = 0;
     yieldMaxLanes = 0;
