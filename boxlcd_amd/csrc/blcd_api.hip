@@ -226,21 +226,26 @@ __global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restr
 // flight with the solver's own semi-implicit Euler step (no damping, bounding circle); it only decides placement, never
 // results.  Keys: 0..31 = impact predicted in that many world steps, 32 = none within 32 steps, 33 = resting on a wall,
 // 40..46 = generic work classes (heaviest first), 47 = asleep.
-constexpr int kBins = 49;   // + bin 0 (ahead of everything): environments suspended in the current fused chunk
+constexpr int kBins = 51;   // + bins 0..2 (ahead of everything): environments suspended at a TOI event / in position iterations / in velocity sweeps
 constexpr int kPredictSteps = 32;
 constexpr int kRebinBlock = 256;
 
 __device__ inline int work_class1(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode);
-__device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode) {
-  // suspended environments first and together: the resuming pass of the chunk then runs them in dense waves
-  const uint32_t prog = __float_as_uint(st[(size_t)schedWordOffset(S->nb, S->nj, S->np) * N + slot]);
-  if ((prog >> 10) & 0x7fu) return 0;
-  if (mode < 0) return 1;       // batches that are not sorted by work class: only the suspended ones move (stable sort)
-  return 1 + work_class1(S, st, N, slot, mode);
+__device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode, int tEnd) {
+  // suspended environments first and together, by what they are suspended at: the launch that resumes them then runs what they
+  // owe in dense, homogeneous waves; environments that have finished the rollout (tEnd > 0) go last
+  const size_t po = (size_t)schedWordOffset(S->nb, S->nj, S->np);
+  const uint32_t prog0 = __float_as_uint(st[po * N + slot]), prog1 = __float_as_uint(st[(po + 1) * N + slot]);
+  if ((prog0 >> 18) & 1u) return 0;
+  if ((prog1 >> 7) & 0x7fu) return 1;
+  if (prog1 & 0x7fu) return 2;
+  if (tEnd > 0 && (int)(prog0 & 0xffffu) >= tEnd) return kBins - 1;
+  if (mode < 0) return 3;       // batches that are not sorted by work class: only the suspended ones move (stable sort)
+  return 3 + work_class1(S, st, N, slot, mode);
 }
 __device__ inline int work_class1(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode) {
-  constexpr int kAll = kBins;          // the bins below this function's own key space: 1 + (0 .. kAll - 2)
-  constexpr int kBins = kAll - 1;
+  constexpr int kAll = kBins;          // this function's own key space: 3 + (0 .. kAll - 4)
+  constexpr int kBins = kAll - 3;
   const int nb = S->nb, nj = S->nj, np = S->np;
   bool anyAwake = false;
   for (int i = 0; i < nb; ++i) anyAwake = anyAwake || st[(size_t)(i * kBodyFields + 12) * N + slot] != 0.0f;
@@ -282,13 +287,13 @@ __device__ inline int work_class1(const DevScene* __restrict__ S, const float* _
 // The three re-bin kernels sort ONE slot range (a cohort, or all slots): st / keys / eid point at the range's first slot, N stays
 // the stride between state fields, n is the number of slots in the range and lo its first slot (slotOf holds absolute slots).
 __global__ __launch_bounds__(kRebinBlock) void rebin_hist_kernel(const DevScene* __restrict__ S, const float* __restrict__ st,
-                                                                 int N, int n, uint8_t* __restrict__ keys, int* __restrict__ counts, int mode) {
+                                                                 int N, int n, uint8_t* __restrict__ keys, int* __restrict__ counts, int mode, int tEnd) {
   __shared__ int h[kBins];
   if (threadIdx.x < kBins) h[threadIdx.x] = 0;
   __syncthreads();
   int slot = blockIdx.x * kRebinBlock + threadIdx.x;
   if (slot < n) {
-    int k = work_class(S, st, N, slot, mode);
+    int k = work_class(S, st, N, slot, mode, tEnd);
     keys[slot] = (uint8_t)k;
     atomicAdd(&h[k], 1);
   }
@@ -562,6 +567,10 @@ struct blcd_handle_s {
   // environment-level scheduling of fused chunks (joint-free classes): passes per chunk (1 = off) and the most
   // lanes of a wave that may still be sweeping for those lanes to be suspended (BLCD_YIELD_PASSES, BLCD_YIELD_LANES)
   int yieldPasses = 1, yieldMaxLanes = 0;
+  // asynchronous rollouts (BLCD_ASYNC=<world steps per launch>): every launch advances every unfinished environment by at most
+  // that many world steps from wherever it stands, suspended ones pay what they owe in dense waves, a re-bin follows every launch
+  int asyncBudget = 0;
+  long long asyncLaunches = 0;
   // goal epilogue (blcd_goal_*): device-resident goals, previous deltas and scratch observation buffers
   blcd_goal_desc goal{};
   bool goalSet = false;
@@ -689,7 +698,7 @@ static int pick_cfg(const DevScene& S) {
 // after the last, so a "launch" of the timing code stays one chunk of the batch
 static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors,
                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, long long actStride = 0, uint8_t* lcdOut = nullptr,
-                       float* obsOut = nullptr, int cohort = -1, int pass = 0, int nPasses = 1, int lcdBits = 0) {
+                       float* obsOut = nullptr, int cohort = -1, int pass = 0, int nPasses = 1, int lcdBits = 0, int stepBudget = 0) {
   const int lanes = h->lanes;
   const int lo = cohort < 0 ? 0 : h->cohortLo[cohort];
   const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
@@ -700,10 +709,10 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
       e0 = h->ev0;
       e1 = h->ev1;
     }
-    if (pass == 0) HIPCHK(hipEventRecord(e0, stream));
+    if (pass == 0 && stepBudget == 0) HIPCHK(hipEventRecord(e0, stream));
   }
   StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
-             pass, pass + 1 < nPasses ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits, nPasses > 1 ? 1 : 0};
+             pass, (pass + 1 < nPasses || stepBudget > 0) ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits, (nPasses > 1 || stepBudget > 0) ? 1 : 0, stepBudget};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \
@@ -711,7 +720,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   BLCD_CONFIGS(X)
 #undef X
   HIPCHK(hipGetLastError());
-  if (cohort < 0 && pass + 1 == nPasses) {
+  if (cohort < 0 && pass + 1 == nPasses && stepBudget == 0) {
     HIPCHK(hipEventRecord(e1, stream));
     h->lastLaunches += 1;
   }
@@ -734,7 +743,7 @@ static int launch_set_poses(blcd_handle h, const int* dIdx, int n, const float* 
 // stable counting sort of slots by work class, within each cohort and on that cohort's stream; swaps the state buffers
 // midChunk: between the passes of a fused chunk (suspended environments to the front; the rest keeps its work-class order, or - in
 // batches that are not sorted by work class at all - its place)
-static int launch_rebin(blcd_handle h, bool midChunk = false) {
+static int launch_rebin(blcd_handle h, bool midChunk = false, int tEnd = 0) {
   const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;   // room for every cohort's block counts (rounding)
   for (int c = 0; c < h->nCohorts; ++c) {
     const int lo = h->cohortLo[c], n = h->cohortLo[c + 1] - lo;
@@ -743,7 +752,7 @@ static int launch_rebin(blcd_handle h, bool midChunk = false) {
     int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
     int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
     hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->dScene, h->st + lo, h->N, n, h->keys + lo, counts,
-                       midChunk && h->rebinEvery <= 0 ? -1 : h->binMode);
+                       midChunk && h->rebinEvery <= 0 ? -1 : h->binMode, tEnd);
     hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, offsets, nBlocks * kBins);
     hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->st + lo, h->st2 + lo, h->N, n, lo, (int)h->words,
                        h->keys + lo, offsets, h->eid + lo, h->eid2 + lo, h->slotOf);
@@ -982,7 +991,16 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     h->rebinEvery = (h->hostScene.nj == 0 && simds > 0 && (long long)n_envs > 64LL * simds) ? 1 : 0;
   }
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
-  if (h->hostScene.nj == 0 && h->hostScene.nb <= 7 && h->hostScene.velIters > kYieldSweeps) {
+  if (h->hostScene.nb <= 7) {
+    if (const char* ev = getenv("BLCD_ASYNC")) h->asyncBudget = atoi(ev) > 0 ? atoi(ev) : 0;
+    if (h->asyncBudget > 0) {
+      h->yieldMaxLanes = 32;
+      if (const char* ev = getenv("BLCD_YIELD_LANES")) h->yieldMaxLanes = atoi(ev);
+      if (h->yieldMaxLanes < 1) h->yieldMaxLanes = 1;
+      if (h->yieldMaxLanes > 64) h->yieldMaxLanes = 64;
+    }
+  }
+  if (h->asyncBudget == 0 && h->hostScene.nj == 0 && h->hostScene.nb <= 7 && h->hostScene.velIters > kYieldSweeps) {
     // measured: chunk-level passes do not pay - a suspended environment's remaining chunk is as long a critical
     // path in the resuming pass as it was in the first - so the default is OFF; the mechanism stays (it is what the
     // schedule-invariance test and the asynchronous scheduler build on): BLCD_YIELD_PASSES=2 BLCD_YIELD_LANES=32 turns it on
@@ -1000,10 +1018,10 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   }
   for (int c = 1; c <= blcd_handle_s::kMaxCohorts; ++c) h->cohortLo[c] = n_envs;
   {
-    int k = h->rebinEvery > 0 && !h->waveTimes ? 2 : 1;     // the re-binned (oversubscribed, joint-free) batches
+    int k = h->rebinEvery > 0 && !h->waveTimes && h->asyncBudget == 0 ? 2 : 1;     // the re-binned (oversubscribed, joint-free) batches
     if (const char* ev = getenv("BLCD_COHORTS")) {
       int q = atoi(ev);
-      k = (q >= 2 && h->rebinEvery > 0 && !h->waveTimes) ? (q > blcd_handle_s::kMaxCohorts ? blcd_handle_s::kMaxCohorts : q) : 1;
+      k = (q >= 2 && h->rebinEvery > 0 && !h->waveTimes && h->asyncBudget == 0) ? (q > blcd_handle_s::kMaxCohorts ? blcd_handle_s::kMaxCohorts : q) : 1;
     }
     // every cohort needs at least one whole wave of slots: small batches (BLCD_REBIN=1 / BLCD_COHORTS on a few environments)
     // get fewer cohorts, down to the single range
@@ -1179,7 +1197,36 @@ static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t*
         chunk = c < 20.0f ? 20 : (c > 200.0f ? 200 : (int)c);
       }
     }
-    if (h->nCohorts > 1) {
+    if (h->asyncBudget > 0 && T <= 60000) {
+      // Asynchronous rollout: no chunk boundaries at all.  Launch after launch, every unfinished environment
+      // advances by at most asyncBudget world steps from its own position; the slot sort after each launch puts the suspended
+      // ones together.  The loop ends when the device counter of unfinished environments reads zero.
+      if ((rc = join_cohort_stream(h))) return rc;
+      const size_t po = (size_t)schedWordOffset(h->hostScene.nb, h->hostScene.nj, h->hostScene.np);
+      HIPCHK(hipMemsetAsync(h->st + po * (size_t)h->N, 0, 2 * (size_t)h->N * sizeof(float), h->stream));   // progress words: everyone at step 0
+      HIPCHK(hipEventRecord(h->evPool[0], h->stream));
+      const int minLaunches = (T * h->hostScene.substeps + h->asyncBudget - 1) / h->asyncBudget;
+      unsigned long long unfinished = 1;
+      int launches = 0;
+      while (unfinished) {
+        HIPCHK(hipMemsetAsync(h->dSchedStats + 3, 0, sizeof(unsigned long long), h->stream));
+        if ((rc = launch_step(h, (const float*)dAct, T, 0, 0, nullptr, nullptr, (long long)h->N * nact, (uint8_t*)dLcd, (float*)dObs, -1, 1, 1, lcdBits,
+                              h->asyncBudget)))
+          return rc;
+        ++launches;
+        if (launches >= minLaunches) {
+          HIPCHK(hipMemcpyAsync(&unfinished, h->dSchedStats + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+          HIPCHK(hipStreamSynchronize(h->stream));
+          if (launches > 64 * minLaunches + 64) return fail(BLCD_ERR_HIP, "blcd_rollout: the asynchronous scheduler made no progress");
+        }
+        if (unfinished && (rc = launch_rebin(h, true, T))) return rc;
+      }
+      HIPCHK(hipEventRecord(h->evPool[1], h->stream));
+      h->asyncLaunches += launches;
+      h->lastLaunches = 1;
+      nLaunch = 1;
+      cohortTimed = true;
+    } else if (h->nCohorts > 1) {
       // two cohorts, two streams, no barrier between chunks: cohort k's chunk i + 1 follows its own chunk i (and its own
       // re-bin) only.  Timed as ONE sequence on the handle's stream: e0 before the first launch, e1 after the other streams have joined.
       HIPCHK(hipEventRecord(h->evPool[0], h->stream));

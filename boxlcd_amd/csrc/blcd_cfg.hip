@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
-                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits) {
+                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits, int stepBudget) {
   uint32_t* const ldsRows = Env<NB, NJ, NP, SH, SCHED>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
@@ -120,42 +120,49 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     return;
   } else {
   // ---- the scheduler's kernel ----
-  // Progress inside a fused chunk (environment-level scheduling): a chunk is stepped in `passes`; pass 0 starts
-  // every environment at env-step 0, a later pass picks each environment up where the previous one left it - finished (the lane
-  // idles), or suspended in the velocity sweeps of one of its islands (the lane resumes that world step first).
+  // Every environment carries its own progress (env-step t, sub-step) and, when it is suspended, what it is suspended at
+  // (state words schedWordOffset.. ).  A launch advances every unfinished environment by at most `stepBudget`
+  // world steps from wherever it stands: a suspended one first pays what it owes (worldStepResume).  A lane whose environment
+  // suspends idles until the next launch - by then the host has sorted the suspended environments together, so that what they
+  // owe (the rest of 180 sweeps / 60 position iterations, a TOI event with its sub-step) runs in dense waves instead of keeping
+  // 63 finished lanes waiting.  pass 0 of a chunk (or the host's memset in asynchronous rollouts) starts everyone at step 0.
   float* const progWord = st + (size_t)schedWordOffset(S->nb, S->nj, S->np) * N + slot;
-  uint32_t prog = (nEnvSteps > 0 && pass > 0) ? __float_as_uint(*progWord) : 0u;
-  int t = (int)(prog & 0xffu), sub = (int)((prog >> 8) & 3u);
+  const bool fresh = nEnvSteps <= 0 || pass == 0;
+  const uint32_t prog = fresh ? 0u : __float_as_uint(progWord[0]);
+  const uint32_t prog1 = fresh ? 0u : __float_as_uint(progWord[N]);
+  int t = (int)(prog & 0xffffu), sub = (int)((prog >> 16) & 3u);
   bool live = t < nEnvSteps;
-  if (nEnvSteps > 0 && !__any(live)) return;     // the whole wave finished the chunk in an earlier pass
+  if (nEnvSteps > 0 && !__any(live)) return;     // the whole wave has finished the rollout / chunk
   const bool fullWave = __ballot(1) == ~0ull;    // every lane of the wave holds an environment (the coalesced frame store needs all 64)
   EnvT env;
   env.load(S, st, N, slot);
   env.profOn = waveTimes != nullptr;
-  env.velMask = (prog >> 10) & 0x7fu;
-  env.islandedMask = (prog >> 17) & 0x7fu;
+  env.toiPending = (prog >> 18) & 1u;
+  env.velMask = prog1 & 0x7fu;
+  env.posMask = (prog1 >> 7) & 0x7fu;
+  env.islandedMask = (prog1 >> 14) & 0x7fu;
   env.yieldMaxLanes = yieldMaxLanes;
 #ifdef BLCD_ABLATION
   if (S->dbgSkip & 8) nEnvSteps = nWorldSteps = 0;
 #endif
   if (nEnvSteps > 0) {
-    // Fused rollout: this wave advances its environments through all nEnvSteps on its own (no grid-wide barrier between
-    // env steps: environments are independent), writing the per-step LCD frame / observation rows as it goes.  Lanes progress
-    // at their own pace: a lane whose environment suspends (worldStep returns true) idles until the next pass.
     const size_t lcdRow = (size_t)S->lcdH * S->lcdW / (lcdBits ? 8 : 1);   // bytes per frame (lcdBits: one bit per pixel)
     const bool mayYield = EnvT::kCanYield && yieldMaxLanes > 0;
-    bool resume = EnvT::kCanYield && env.velMask != 0;
+    bool pending = env.toiPending || (env.velMask | env.posMask) != 0;
+    const bool enteredLive = live;
+    int budget = stepBudget > 0 ? stepBudget : 0x7fffffff;
     while (__any(live)) {
-      bool emitNow = false;
+      bool emitNow = false, stop = false;
       if (live) {
-        bool suspended = false;
-        if (resume) {
-          env.worldStepResume();
-          resume = false;
+        bool suspended;
+        if (pending) {
+          suspended = env.worldStepResume(mayYield);
+          pending = false;
         } else {
           if (sub == 0) env.setMotorSpeeds(actions ? actions + (size_t)t * actStride : nullptr, N, e);
           suspended = env.worldStep(mayYield);
         }
+        stop = --budget <= 0;
         if (suspended) live = false;
         else if (++sub == S->substeps) {
           sub = 0;
@@ -183,9 +190,8 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
             o[1] = make_uint4(w[4], w[5], w[6], w[7]);
           }
         } else if (lcdOut && S->lcdW == 16 && fullWave) {
-          // 16x16 frames: 256 B = one dword per lane.  Writing each lane's own frame row by row makes every store touch 64
-          // different cache lines; instead the emitting lanes park their 16 row masks in LDS and the WHOLE wave writes one frame
-          // per store instruction (fully coalesced): frame k = the environment held by lane k, at that lane's own env-step.
+          // 16x16 frames: 256 B = one dword per lane.  The emitting lanes park their 16 row masks in LDS and the WHOLE wave writes
+          // one frame per store instruction (fully coalesced): frame k = the environment of lane k, at that lane's own env-step.
           const int lane = (int)threadIdx.x;
           if (emitNow) {
             uint32_t rows[16];
@@ -198,26 +204,14 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           const int row = lane >> 2, x0 = (lane & 3) * 4;   // this lane's 4 pixels of any frame
           unsigned long long em = __ballot(emitNow);
-          if (em == ~0ull) {
-            uint8_t* frames = lcdOut + (size_t)__builtin_amdgcn_readfirstlane(t) * N * lcdRow;   // lanes in step: one base
-            const bool sameT = __all(t == __builtin_amdgcn_readfirstlane(t));
-            for (int k = 0; k < 64; ++k) {
-              const int ek = __builtin_amdgcn_readlane(e, k);
-              if (!sameT) frames = lcdOut + (size_t)__builtin_amdgcn_readlane(t, k) * N * lcdRow;
-              const uint32_t m = ldsRows[k * 17 + row];
-              const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
-              *reinterpret_cast<uint32_t*>(frames + (size_t)ek * 256 + 4 * lane) = px;
-            }
-          } else {
-            while (em) {
-              const int k = __ffsll((long long)em) - 1;
-              em &= em - 1;
-              const int ek = __builtin_amdgcn_readlane(e, k);
-              const int tk = __builtin_amdgcn_readlane(t, k);
-              const uint32_t m = ldsRows[k * 17 + row];
-              const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
-              *reinterpret_cast<uint32_t*>(lcdOut + ((size_t)tk * N + ek) * 256 + 4 * lane) = px;
-            }
+          while (em) {
+            const int k = __ffsll((long long)em) - 1;
+            em &= em - 1;
+            const int ek = __builtin_amdgcn_readlane(e, k);
+            const int tk = __builtin_amdgcn_readlane(t, k);
+            const uint32_t m = ldsRows[k * 17 + row];
+            const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+            *reinterpret_cast<uint32_t*>(lcdOut + ((size_t)tk * N + ek) * 256 + 4 * lane) = px;
           }
           __builtin_amdgcn_wave_barrier();
         } else if (emitNow) {
@@ -231,15 +225,21 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
         if (!ok) env.fault |= FAULT_ELLIPSE;
       }
       if (emitNow && ++t >= nEnvSteps) live = false;
+      if (stop) live = false;
     }
-    *progWord = __uint_as_float((uint32_t)t | ((uint32_t)sub << 8) | (env.velMask << 10) | (env.islandedMask << 17));
-    if (schedStats && EnvT::kCanYield) {   // per pass class (first / later): lanes that entered live, lanes that left suspended, waves
-      const unsigned long long in_ = __ballot(1), sus_ = __ballot(env.velMask != 0), lv_ = __ballot((int)(prog & 0xffu) < nEnvSteps);
+    progWord[0] = __uint_as_float((uint32_t)t | ((uint32_t)sub << 16) | ((uint32_t)env.toiPending << 18));
+    progWord[N] = __uint_as_float(env.velMask | (env.posMask << 7) | (env.islandedMask << 14));
+    if (schedStats) {
+      // [0..2] / [4..6]: first / later passes: lanes that entered live, lanes that left suspended, waves; [3]: environments that
+      // have not reached the last env-step yet (the host zeroes it before a launch of an asynchronous rollout)
+      const bool susp = env.toiPending || (env.velMask | env.posMask) != 0;
+      const unsigned long long in_ = __ballot(1), sus_ = __ballot(susp), lv_ = __ballot(enteredLive), un_ = __ballot(t < nEnvSteps);
       if ((int)threadIdx.x == __ffsll((long long)in_) - 1) {
         unsigned long long* o = schedStats + (pass > 0 ? 4 : 0);
         atomicAdd(o, (unsigned long long)__popcll(lv_));
         atomicAdd(o + 1, (unsigned long long)__popcll(sus_));
         atomicAdd(o + 2, 1ull);
+        if (un_) atomicAdd(schedStats + 3, (unsigned long long)__popcll(un_));
       }
     }
   } else {
@@ -303,16 +303,16 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 #define BLCD_NAME(p, a, b, c, d) BLCD_PASTE5(p, a, b, c, d)
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
-  // the scheduler's kernel exists for the classes it can act on (joint-free, see Env::kCanYield) and runs only when asked for
-  if constexpr (BLCD_NJ == 0 && BLCD_NB <= 7) {
+  // the scheduler's kernel exists for the classes it can act on (see Env::kCanYield) and runs only when asked for
+  if constexpr (BLCD_NB <= 7) {
     if (A.sched) {
       hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, true>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                         A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits);
+                         A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget);
       return;
     }
   }
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, false>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits);
+                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {
   hipLaunchKernelGGL((set_poses_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(64), 0, stream, A.S, A.st, A.N, A.slotOf, A.idxs, A.n,

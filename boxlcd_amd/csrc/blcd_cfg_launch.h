@@ -31,6 +31,7 @@ struct StepArgs {
   unsigned long long* schedStats;   // 8 counters (see blcd_sched_stats) or null
   int lcdBits;        // lcdOut holds frames at one bit per pixel (blcd_rollout_bits)
   int sched;          // launch the scheduler's kernel (step_kernel<..., true>): passes / suspension / resumption
+  int stepBudget;     // scheduler kernel: world steps an environment may advance in this launch (0 = to the end)
 };
 struct SetPosesArgs {
   const DevScene* S;

@@ -853,10 +853,13 @@ struct RegIsland {
   }
 
   // position iterations; returns positionSolved
-  __device__ __forceinline__ bool positionIterations(int posIters, int* itersDone) {
+  // startIt / yieldAt / yieldMaxLanes / yielded: as for velocitySweeps - an island still unsolved after `yieldAt` iterations
+  // while at most yieldMaxLanes lanes of the wave are, stops there (the positions reached so far are the whole state needed)
+  __device__ __forceinline__ bool positionIterations(int posIters, int* itersDone, int startIt = 0, int yieldAt = 0, int yieldMaxLanes = 0,
+                                                     bool* yielded = nullptr) {
     bool positionSolved = false;
     int n = 0;
-    for (int it = 0; it < posIters; ++it) {
+    for (int it = startIt; it < posIters; ++it) {
       float minSeparation = 0.0f;
 #pragma unroll
       for (int k = 0; k < NCR; ++k)
@@ -875,6 +878,12 @@ struct RegIsland {
       if (contactsOkay && jointsOkay) {
         positionSolved = true;
         break;
+      }
+      if (yieldAt > 0 && it == yieldAt - 1 && posIters > yieldAt) {
+        if (__popcll(__ballot(1)) <= yieldMaxLanes) {
+          *yielded = true;
+          break;
+        }
       }
     }
     *itersDone = n;

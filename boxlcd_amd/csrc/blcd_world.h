@@ -92,17 +92,23 @@ struct DevScene {
   DevObs obs[96];
 };
 
-// Scheduling words, appended after everything else (so no other offset moves): one progress word (env-step and sub-step
-// reached inside the current fused chunk, seeds of the islands suspended in their velocity sweeps, bodies that were in an
-// island this world step) and, per body, the velocity a suspended island's sweeps had reached (v.x v.y w).  See Env::solve.
+// Scheduling words, appended after everything else (so no other offset moves): two progress words (env-step and sub-step
+// reached inside the current rollout / chunk, what the environment is suspended at, bodies that were in an island this world
+// step) and, per body, the velocity a suspended island's sweeps had reached (v.x v.y w).  See Env::solve.
 BLCD_HD static inline int schedWordOffset(int nb, int nj, int np) {
   return nb * kBodyFields + np * kPairFields + nj * kJointFields + kWorldFields + (np + 3) / 4;
 }
-BLCD_HD static inline int stateWords(int nb, int nj, int np) { return schedWordOffset(nb, nj, np) + 1 + 3 * nb; }
+BLCD_HD static inline int stateWords(int nb, int nj, int np) { return schedWordOffset(nb, nj, np) + 2 + 3 * nb; }
+// word 0: env-step reached (16 bits) | sub-step (2) << 16 | suspended at a TOI event << 18
+// word 1: seeds of the islands suspended in their velocity sweeps (7 bits) | in their position iterations << 7 | islanded bodies << 14
+constexpr uint32_t kProgPendingMask1 = 0x3fffu;
 // A lane whose joint-free island has not converged after this many velocity sweeps (= the window of the short-cycle detector)
 // may suspend its environment instead of dragging the wave through the remaining <= 156 sweeps (scheduling only: the
 // environment resumes in a later pass of the same chunk at exactly this sweep, with exactly this solver state)
 constexpr int kYieldSweeps = 24;
+// ... and an island whose position constraints are still unsolved after this many of the <= 60 position iterations
+// (mean 8; 7 % of the jointed islands never meet the tolerance and run all of them)
+constexpr int kYieldPosIters = 12;
 
 struct VCPoint {
   Vec2 rA, rB;
@@ -326,10 +332,12 @@ struct Env {
   uint8_t ij[NJ > 0 ? NJ : 1];
 
   // --- environment-level scheduling (fused rollouts) ---
-  static constexpr bool kCanYield = SCHED && NJ == 0 && NB <= 7;   // joint-free classes: their sweeps have an early exit that stragglers miss
+  static constexpr bool kCanYield = SCHED && NB <= 7;   // suspension points: velocity sweep 24 of a joint-free island, position iteration 12 of a staged island, the first TOI event
   float* gst;            // this slot's column of the state array (word f at gst[f * gN]): suspended velocities go straight there
   int gN;
   uint32_t velMask;      // seeds of the islands suspended in their velocity sweeps
+  uint32_t posMask;      // seeds of the islands suspended in their position iterations
+  bool toiPending;       // the world step is suspended at its first TOI event (SolveTOI restarts from scratch: nothing it did so far is kept)
   uint32_t islandedMask; // bodies that were in an island when the world step was suspended (SynchronizeFixtures still owed)
   int yieldMaxLanes;     // suspend only when at most this many lanes of the wave are still sweeping (0 = never)
 
@@ -343,6 +351,8 @@ struct Env {
       gN = N;
     }
     velMask = 0;
+    posMask = 0;
+    toiPending = false;
     islandedMask = 0;
     yieldMaxLanes = 0;
     if constexpr (kGenLds) {   // 6 words x NB bodies x 64 lanes (30 KB for NB = 20)
@@ -1466,7 +1476,7 @@ struct Env {
   }
 
   // suspended-velocity words of body i (schedWordOffset + 1 + 3 i ..)
-  __device__ __forceinline__ float* susWords(int i) const { return gst + (size_t)(schedWordOffset(S->nb, S->nj, S->np) + 1 + 3 * i) * gN; }
+  __device__ __forceinline__ float* susWords(int i) const { return gst + (size_t)(schedWordOffset(S->nb, S->nj, S->np) + 2 + 3 * i) * gN; }
 
   // ------------------------------------------------------------------------------------------------
   // b2Island::Solve for the island {bodies in ibmask, contacts ic[0..nic), joints ij[0..nij)}
@@ -1537,8 +1547,12 @@ struct Env {
     static_assert(!kRegCtLds || RegI::kCtLdsWords >= 64 * 17, "frame rows must fit the contact block");
     return reinterpret_cast<uint32_t*>(ctLdsBase());
   }
-  template <bool RESUME = false>   // see islandSolve
+  // MODE 0: the whole island solve; 1: resumed inside the velocity sweeps (see islandSolve); 2: resumed inside the position
+  // iterations - velocities, impulses and the integrated positions are final and already in place, so only the position rows and
+  // the position-constraint halves of the contacts / joints are staged and the loop continues at iteration kYieldPosIters
+  template <int MODE = 0>
   __device__ __forceinline__ bool islandSolveReg(uint32_t ibmask, int nic, int nij, float h, float dtRatio, int seed = 0, bool mayYield = false) {
+    constexpr bool RESUME = MODE == 1;
 #ifdef BLCD_PROF_SOLVE
     const unsigned long long psE_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1555,7 +1569,7 @@ struct Env {
       bool in = i < nb && ((ibmask >> i) & 1);
       Vec2 v_ = v[i];
       float w_ = w[i];
-      if (in) {
+      if (in && MODE != 2) {
         c0[i] = c[i];
         a0[i] = a[i];
         v_ += h * (1.0f * gravity + invMass[i] * V2(0.0f, 0.0f));
@@ -1603,10 +1617,13 @@ struct Env {
         }
       }
     }
+    if constexpr (MODE != 2) {
 #pragma unroll
     for (int k = 0; k < kRegC; ++k)
       if (k < nic) R.initContact(k, R.ct[k], mans[k]);
-    if constexpr (RESUME && kCanYield) {
+    }
+    if constexpr (MODE == 2) {
+    } else if constexpr (RESUME && kCanYield) {
       // the sweeps' own state as it was at suspension: island velocities, accumulated impulses (stored raw in the manifolds)
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -1650,7 +1667,13 @@ struct Env {
           r.imp = jimp[j];
           r.motor = jmotor[j];
           r.limit = jlimit[j];
-          R.initJoint(r, dtRatio);
+          if constexpr (MODE == 2) {   // b2RevoluteJoint::SolvePositionConstraints reads m_motorMass: same expression as initJoint
+            float motorMass = invI[r.A] + invI[r.B];
+            if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
+            r.motorMass = motorMass;
+          } else {
+            R.initJoint(r, dtRatio);
+          }
         }
       }
     }
@@ -1661,6 +1684,7 @@ struct Env {
 #endif
 #endif
     bool yielded = false;
+    if constexpr (MODE != 2) {
     int sweeps = R.velocitySweeps(S->velIters, h, nullptr, RESUME ? kYieldSweeps : 0,
                                   (kCanYield && !RESUME && mayYield && nij == 0) ? kYieldSweeps : 0, yieldMaxLanes, &yielded);
 #ifdef BLCD_PROF_SOLVE
@@ -1738,28 +1762,33 @@ struct Env {
         R.setVel(i, BodyVel{v_, w_});
       }
     }
+    }   // MODE != 2
     int pit = 0;
 #ifdef BLCD_PROF_SOLVE
     unsigned long long ps2_ = __builtin_amdgcn_s_memtime();
 #endif
-    bool positionSolved = R.positionIterations(S->posIters, &pit);
+    bool posYielded = false;
+    bool positionSolved = R.positionIterations(S->posIters, &pit, MODE == 2 ? kYieldPosIters : 0,
+                                               (kCanYield && MODE != 2 && mayYield) ? kYieldPosIters : 0, yieldMaxLanes, &posYielded);
 #ifdef BLCD_PROF_SOLVE
     prof[5] += __builtin_amdgcn_s_memtime() - ps2_;
 #endif
-    // copy back
+    // copy back (a position-suspended island too: what the iterations reached so far IS their state; its velocities are final)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       if (i < nb && ((ibmask >> i) & 1)) {
         const BodyPos bp_ = R.getPos(i);
-        const BodyVel bv_ = R.getVel(i);
         c[i] = bp_.c;
         a[i] = bp_.a;
-        v[i] = bv_.v;
-        w[i] = bv_.w;
-        syncTransform(i);
+        if constexpr (MODE != 2) {
+          const BodyVel bv_ = R.getVel(i);
+          v[i] = bv_.v;
+          w[i] = bv_.w;
+        }
+        if (!posYielded) syncTransform(i);
       }
     }
-    if constexpr (NJ > 0) {
+    if constexpr (NJ > 0 && MODE != 2) {
 #pragma unroll
       for (int k = 0; k < NJ; ++k) {
         if (k < nij) {
@@ -1768,6 +1797,12 @@ struct Env {
           jmotor[j] = R.jt[k].motor;
           jlimit[j] = R.jt[k].limit;
         }
+      }
+    }
+    if constexpr (kCanYield) {
+      if (posYielded) {
+        posMask |= 1u << seed;
+        return true;
       }
     }
     float minSleepTime = kMaxFloat;
@@ -1900,10 +1935,11 @@ struct Env {
   // the untouched world-step-start state (same inputs, same arithmetic, same values - the bias terms need the pre-solve
   // velocities, which is why those stay in place), then the sweeps' own state - island velocities and accumulated impulses - is
   // put back and the loop continues at sweep kYieldSweeps.  Returns true when the island suspends (never when RESUME).
-  template <bool RESUME = false>
+  template <int MODE = 0>   // 0 fresh, 1 resume in the velocity sweeps, 2 resume in the position iterations (staged islands only)
   __device__ __forceinline__ bool islandSolve(uint32_t ibmask, int nic, int nij, float h, float dtRatio, int seed = 0, bool mayYield = false) {
+    constexpr bool RESUME = MODE == 1;
     if constexpr (kUseReg) {
-      if (nic <= kRegC) return islandSolveReg<RESUME>(ibmask, nic, nij, h, dtRatio, seed, mayYield);
+      if (MODE == 2 || nic <= kRegC) return islandSolveReg<MODE>(ibmask, nic, nij, h, dtRatio, seed, mayYield);
     }
     const int nb = S->nb;
     Vec2 gravity = S->gravity;
@@ -2060,10 +2096,11 @@ struct Env {
     }
   }
 
-  // b2World::Solve.  Returns true when an island suspended in its velocity sweeps (joint-free classes, fused rollouts): the rest of
-  // the world step - that island's integration / position solve, SynchronizeFixtures of every islanded body, FindNewContacts,
-  // SolveTOI - is then owed, and solve<true> pays it in a later pass: it re-discovers the suspended islands from their seeds
-  // (velMask; same seed, same contact list, same flags => same DFS order), resumes them, and runs the tail.
+  // b2World::Solve.  Returns true when an island suspended (scheduler kernels only): in its velocity sweeps (velMask) or in its
+  // position iterations (posMask).  The rest of the world step - that island's remaining solve, SynchronizeFixtures of every
+  // islanded body, FindNewContacts, SolveTOI - is then owed, and solve<true> pays it in a later launch: it re-discovers the
+  // suspended islands from their seeds (same seed, same contact list, same flags => same DFS order), resumes each where it
+  // stopped, and runs the tail.  A resumed island can suspend again (velocity sweeps -> position iterations).
   template <bool RESUME = false>
   __device__ __forceinline__ bool solve(float h, float dtRatio, bool mayYield = false) {
     if constexpr (NB == 1) {
@@ -2082,13 +2119,13 @@ struct Env {
           ic.set(nic++, s);
           pflags.set(s, fl | PF_ISLAND);
         }
-        if (islandSolve<RESUME>(1u, nic, 0, h, dtRatio, 0, mayYield)) {
+        velMask = 0;
+        if (islandSolve<RESUME ? 1 : 0>(1u, nic, 0, h, dtRatio, 0, mayYield)) {
           islandedMask = 1u;
           return true;
         }
         synchronizeFixtures(0);
       }
-      velMask = 0;
       findNewContacts(false);
       return false;
     }
@@ -2096,7 +2133,23 @@ struct Env {
     uint32_t bodyIsland = 0, jointIsland = 0;
     bool anyYield = false;
     for (int k = 0; k < nc; ++k) pflags.clearBits(wl.get(k), PF_ISLAND);
-    if constexpr (NJ > 0) {
+    if constexpr (RESUME) {
+      uint32_t vseeds = velMask, pseeds = posMask;
+      velMask = 0;
+      posMask = 0;
+      while (vseeds | pseeds) {
+        const int seed = 31 - __clz((int)(vseeds | pseeds));
+        const bool inPos = (pseeds >> seed) & 1;
+        vseeds &= ~(1u << seed);
+        pseeds &= ~(1u << seed);
+        uint32_t ibmask = 0;
+        int nic = 0, nij = 0;
+        islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
+        if (inPos) anyYield = islandSolve<2>(ibmask, nic, nij, h, dtRatio, seed, false) || anyYield;
+        else anyYield = islandSolve<1>(ibmask, nic, nij, h, dtRatio, seed, mayYield) || anyYield;
+      }
+      bodyIsland = islandedMask;
+    } else if constexpr (NJ > 0) {
       // Islands are disjoint, so the ORDER in which they are solved changes nothing - but in a wave it decides whether the
       // lanes' expensive (jointed) islands run in the same loop iteration.  With the seed loop alone, an environment whose
       // free object touches the robot solves the robot at the object's seed and its neighbour lane solves it one seed later:
@@ -2125,22 +2178,10 @@ struct Env {
           uint32_t ibmask = 0;
           int nic = 0, nij = 0;
           islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
-          islandSolve(ibmask, nic, nij, h, dtRatio);
+          anyYield = islandSolve(ibmask, nic, nij, h, dtRatio, seed, mayYield) || anyYield;
         }
       }
       bodyIsland = allBodies;
-    } else if constexpr (RESUME) {
-      uint32_t seeds = velMask;
-      velMask = 0;
-      while (seeds) {
-        const int seed = 31 - __clz((int)seeds);
-        seeds &= ~(1u << seed);
-        uint32_t ibmask = 0;
-        int nic = 0, nij = 0;
-        islandDFS(seed, bodyIsland, jointIsland, ibmask, nic, nij);
-        islandSolve<true>(ibmask, nic, nij, h, dtRatio, seed, false);
-      }
-      bodyIsland = islandedMask;
     } else {
       for (int seed = NB - 1; seed >= 0; --seed) {
         if (seed >= nb) continue;
@@ -2153,7 +2194,7 @@ struct Env {
       }
     }
     if (anyYield) {
-      islandedMask = bodyIsland;
+      if constexpr (!RESUME) islandedMask = bodyIsland;
       return true;
     }
 #ifdef BLCD_PROF_SOLVE2
@@ -2214,7 +2255,11 @@ struct Env {
     xfp[i] = c[i] - Mul(q[i], lc[i]);
   }
 
-  __device__ __forceinline__ void solveTOI(float dt) {
+  // mayYield (scheduler kernels): returns true - with NOTHING of what it did so far kept - when there is a TOI event to process
+  // and the caller should suspend the environment; the resuming launch calls solveTOI again from the same state, which finds
+  // the same event first (everything up to it is a pure function of the state: the TOI cache, flags and counters live only
+  // inside one SolveTOI)
+  __device__ __forceinline__ bool solveTOI(float dt, bool mayYield = false) {
 #ifdef BLCD_PROF_TOI
 #define PT(k_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[k_] += n_ - pt_; pt_ = n_; } while (0)
     unsigned long long pt_ = __builtin_amdgcn_s_memtime();
@@ -2383,6 +2428,9 @@ struct Env {
       }
       PT(4);
       if (minSlot < 0 || 1.0f - 10.0f * kEpsilon < minAlpha) break;
+      if constexpr (kCanYield) {
+        if (mayYield && guard == 0 && __popcll(__ballot(1)) <= yieldMaxLanes) return true;
+      }
 
 #ifdef BLCD_PROF_TOI2
 #define QT(k_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) prof[k_] += n_ - qt_; qt_ = n_; } while (0)
@@ -2503,16 +2551,26 @@ struct Env {
     PT(5);
 #undef PT
 #undef QT
+    return false;
   }
 
   // b2World::Step
-  // the owed part of a world step that was suspended in solve() (see there)
-  __device__ __forceinline__ void worldStepResume() {
+  // the owed part of a suspended world step (see solve / solveTOI); returns true when it suspends again at a later point
+  __device__ __forceinline__ bool worldStepResume(bool mayYield) {
     const float dt = S->dt;
     const float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
-    solve<true>(dt, inv_dt0 * dt, false);
-    solveTOI(dt);
+    if (velMask | posMask) {
+      if (solve<true>(dt, inv_dt0 * dt, mayYield)) return true;
+      islandedMask = 0;
+    }
+    const bool atToi = toiPending;   // resumed AT its TOI event: that event is processed now, whatever the wave looks like
+    toiPending = false;
+    if (solveTOI(dt, mayYield && !atToi)) {
+      toiPending = true;
+      return true;
+    }
     inv_dt0 = inv_dt;
+    return false;
   }
 
   // returns true when the environment suspended (mayYield only; the caller resumes it with worldStepResume in a later pass)
@@ -2538,7 +2596,12 @@ struct Env {
       if (solve(dt, dtRatio, mayYield)) return true;
     }
     unsigned long long c2_ = profOn ? __builtin_amdgcn_s_memtime() : 0;
-    if (!(skip & 4)) solveTOI(dt);
+    if (!(skip & 4)) {
+      if (solveTOI(dt, mayYield)) {
+        toiPending = true;
+        return true;
+      }
+    }
     if (profOn) {
       unsigned long long c3_ = __builtin_amdgcn_s_memtime();
 #if !defined(BLCD_PROF_TOI) && !defined(BLCD_PROF_TOI2)

@@ -381,3 +381,40 @@ def test_suspending_straggler_environments_changes_nothing(monkeypatch, name, n)
   idx = np.random.RandomState(2).choice(n, 64, replace=False)
   _, _, olcd, ost = pyb2o.rollout(d, poses[idx], sel[idx], None, T, threads=8)
   assert (ost == res[1][2][0][idx]).all() and (olcd == res[1][0][-1][idx]).all()
+
+
+@pytest.mark.parametrize('name,n', [('Urchin', 2000), ('LuxoBall', 2000), ('UrchinBalls', 700), ('Object2', 4000), ('Dropbox', 4000), ('Luxo', 333)])
+def test_asynchronous_rollouts_change_nothing(monkeypatch, name, n):
+  """BLCD_ASYNC=<k>: no chunk boundaries - every launch advances every unfinished environment by at most k world steps from its own
+  position; an environment suspends at velocity sweep 24 of a joint-free island, at position iteration 12 of a staged island or at
+  its first TOI event when few lanes of its wave are in the same situation, and pays what it owes in a later launch, sorted next
+  to its like.  Scheduling only: frames, observations and the full state equal the plain rollout and the oracle."""
+  T = 40
+  env, poses, sel = parity.make_batch(name, n, 33)
+  acts = env.sample_actions(T)
+  d = env.scene.desc
+  res = []
+  for knobs in ({}, {'BLCD_ASYNC': '1'}, {'BLCD_ASYNC': '3', 'BLCD_YIELD_LANES': '64'}, {'BLCD_ASYNC': '7', 'BLCD_YIELD_LANES': '8'}):
+    for k in ('BLCD_ASYNC', 'BLCD_YIELD_LANES'):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in knobs.items():
+      monkeypatch.setenv(k, v)
+    h = Handle(d, n, 0)
+    h.reset(None, poses, sel)
+    lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+    obs = np.zeros((T, n, d.n_obs), np.float32)
+    h.rollout(acts, T, lcd, obs)
+    h.step(acts[0], 1)                                   # the plain path right after an asynchronous rollout
+    res.append((lcd, obs, [x.copy() for x in h.debug_dump()]))
+    assert not h.faults().any()
+    if knobs:
+      s = h.sched_stats()
+      assert s['later_suspended'] > 0, s                 # the policy did suspend environments
+    h.close()
+  for b in res[1:]:
+    assert (res[0][0] == b[0]).all() and (res[0][1] == b[1]).all()
+    for x, y in zip(res[0][2], b[2]):
+      assert (x == y).all()
+  idx = np.random.RandomState(2).choice(n, 48, replace=False)
+  _, _, olcd, ost = pyb2o.rollout(d, poses[idx], sel[idx], acts[:, idx], T, threads=8)
+  assert (olcd == res[1][0][-1][idx]).all()
