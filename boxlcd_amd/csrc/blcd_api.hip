@@ -571,6 +571,9 @@ struct blcd_handle_s {
   // that many world steps from wherever it stands, suspended ones pay what they owe in dense waves, a re-bin follows every launch
   int asyncBudget = 0;
   long long asyncLaunches = 0;
+  // in-wave batching (BLCD_WAVE_BATCH=<lanes>): the plain chunked rollout on the scheduler's kernel - a suspended lane resumes
+  // inside the same launch, together with the other lanes of its wave that are owed the same kind of work
+  int waveBatch = 0;
   // goal epilogue (blcd_goal_*): device-resident goals, previous deltas and scratch observation buffers
   blcd_goal_desc goal{};
   bool goalSet = false;
@@ -712,7 +715,8 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
     if (pass == 0 && stepBudget == 0) HIPCHK(hipEventRecord(e0, stream));
   }
   StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
-             pass, (pass + 1 < nPasses || stepBudget > 0) ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits, (nPasses > 1 || stepBudget > 0) ? 1 : 0, stepBudget};
+             pass, (pass + 1 < nPasses || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits,
+             (nPasses > 1 || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? 1 : 0, stepBudget, stepBudget > 0 || nPasses > 1 ? 0 : h->waveBatch};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \
@@ -1000,7 +1004,16 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
       if (h->yieldMaxLanes > 64) h->yieldMaxLanes = 64;
     }
   }
-  if (h->asyncBudget == 0 && h->hostScene.nj == 0 && h->hostScene.nb <= 7 && h->hostScene.velIters > kYieldSweeps) {
+  if (h->hostScene.nb <= 7 && h->asyncBudget == 0) {
+    if (const char* ev = getenv("BLCD_WAVE_BATCH")) h->waveBatch = atoi(ev) > 0 ? atoi(ev) : 0;
+    if (h->waveBatch > 0) {
+      h->yieldMaxLanes = 16;
+      if (const char* ev = getenv("BLCD_YIELD_LANES")) h->yieldMaxLanes = atoi(ev);
+      if (h->yieldMaxLanes < 1) h->yieldMaxLanes = 1;
+      if (h->yieldMaxLanes > 64) h->yieldMaxLanes = 64;
+    }
+  }
+  if (h->asyncBudget == 0 && h->waveBatch == 0 && h->hostScene.nj == 0 && h->hostScene.nb <= 7 && h->hostScene.velIters > kYieldSweeps) {
     // measured: chunk-level passes do not pay - a suspended environment's remaining chunk is as long a critical
     // path in the resuming pass as it was in the first - so the default is OFF; the mechanism stays (it is what the
     // schedule-invariance test and the asynchronous scheduler build on): BLCD_YIELD_PASSES=2 BLCD_YIELD_LANES=32 turns it on

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
-                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits, int stepBudget) {
+                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits, int stepBudget, int resumeBatch) {
   uint32_t* const ldsRows = Env<NB, NJ, NP, SH, SCHED>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
@@ -153,18 +153,33 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     int budget = stepBudget > 0 ? stepBudget : 0x7fffffff;
     while (__any(live)) {
       bool emitNow = false, stop = false;
-      if (live) {
+      // In-wave batching (resumeBatch > 0): a suspended lane does not wait for the next launch but for company - the wave runs
+      // the resumption code once for everyone who is owed the same kind of work (the rest of a solve / a TOI event) as soon as
+      // resumeBatch lanes are, or when nobody has anything else to do; until then the others carry on with their world steps.
+      // Lanes of one wave may therefore stand at different env-steps: phases are code, not time.
+      bool runResume = pending, runStep = !pending;
+      if (resumeBatch > 0) {
+        const bool wantSolve = live && pending && !env.toiPending, wantToi = live && pending && env.toiPending;
+        const int nSolve = __popcll(__ballot(wantSolve)), nToi = __popcll(__ballot(wantToi));
+        const bool anyStep = __any(live && !pending);
+        const bool pickSolve = nSolve > 0 && nSolve >= nToi && (nSolve >= resumeBatch || !anyStep);
+        const bool pickToi = !pickSolve && nToi > 0 && (nToi >= resumeBatch || !anyStep);
+        runResume = (pickSolve && wantSolve) || (pickToi && wantToi);
+        runStep = !(pickSolve || pickToi) && !pending;
+      }
+      if (live && (runResume || runStep)) {
         bool suspended;
-        if (pending) {
+        if (runResume) {
           suspended = env.worldStepResume(mayYield);
-          pending = false;
         } else {
           if (sub == 0) env.setMotorSpeeds(actions ? actions + (size_t)t * actStride : nullptr, N, e);
           suspended = env.worldStep(mayYield);
         }
+        pending = suspended;
         stop = --budget <= 0;
-        if (suspended) live = false;
-        else if (++sub == S->substeps) {
+        if (suspended) {
+          if (resumeBatch <= 0) live = false;     // waits for the next launch
+        } else if (++sub == S->substeps) {
           sub = 0;
           emitNow = true;
         }
@@ -307,12 +322,12 @@ void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipS
   if constexpr (BLCD_NB <= 7) {
     if (A.sched) {
       hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, true>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                         A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget);
+                         A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget, A.resumeBatch);
       return;
     }
   }
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, false>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget);
+                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget, A.resumeBatch);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {
   hipLaunchKernelGGL((set_poses_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(64), 0, stream, A.S, A.st, A.N, A.slotOf, A.idxs, A.n,

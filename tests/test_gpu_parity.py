@@ -394,8 +394,9 @@ def test_asynchronous_rollouts_change_nothing(monkeypatch, name, n):
   acts = env.sample_actions(T)
   d = env.scene.desc
   res = []
-  for knobs in ({}, {'BLCD_ASYNC': '1'}, {'BLCD_ASYNC': '3', 'BLCD_YIELD_LANES': '64'}, {'BLCD_ASYNC': '7', 'BLCD_YIELD_LANES': '8'}):
-    for k in ('BLCD_ASYNC', 'BLCD_YIELD_LANES'):
+  for knobs in ({}, {'BLCD_ASYNC': '1'}, {'BLCD_ASYNC': '3', 'BLCD_YIELD_LANES': '64'}, {'BLCD_ASYNC': '7', 'BLCD_YIELD_LANES': '8'},
+                {'BLCD_WAVE_BATCH': '12'}, {'BLCD_WAVE_BATCH': '3', 'BLCD_YIELD_LANES': '40'}):   # in-wave batching: resumption inside the launch
+    for k in ('BLCD_ASYNC', 'BLCD_YIELD_LANES', 'BLCD_WAVE_BATCH'):
       monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
       monkeypatch.setenv(k, v)
@@ -407,7 +408,7 @@ def test_asynchronous_rollouts_change_nothing(monkeypatch, name, n):
     h.step(acts[0], 1)                                   # the plain path right after an asynchronous rollout
     res.append((lcd, obs, [x.copy() for x in h.debug_dump()]))
     assert not h.faults().any()
-    if knobs:
+    if 'BLCD_ASYNC' in knobs:
       s = h.sched_stats()
       assert s['later_suspended'] > 0, s                 # the policy did suspend environments
     h.close()

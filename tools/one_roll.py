@@ -9,12 +9,13 @@ d = venv.scene.desc
 h = Handle(d, N, 0)
 poses, sel = venv.sample_initial(N)
 h.reset(None, poses, sel)
-h.rollout(None, 40)      # settle a bit (untraced interest)
+acts = venv.sample_actions(40 + T)
+h.rollout(acts[:40], 40)      # settle a bit (untraced interest)
 torch.cuda.synchronize()
 h.sched_stats()
 import time
 t0 = time.perf_counter()
-h.rollout(None, T)
+h.rollout(np.ascontiguousarray(acts[40:]), T)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 s = h.sched_stats()
