@@ -20,6 +20,8 @@ SYMBOLS = {
     'blcd_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_set_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'blcd_reset_sampled': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_int32]),
+    'blcd_sample_reseed': (C.c_int, [C.c_void_p]),
     'blcd_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_rollout_bits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_goal_set': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -108,6 +110,12 @@ def _ptr(x):
   return x.ctypes.data_as(C.c_void_p)
 
 
+class SampleOp(C.Structure):
+  """blcd_sample_op (include/boxlcd.h): one instruction of a scene's reset-sampling program"""
+  _fields_ = [('kind', C.c_int32), ('d', C.c_int32), ('a', C.c_int32), ('b', C.c_int32), ('body', C.c_int32), ('parent', C.c_int32),
+              ('f', C.c_double * 5)]
+
+
 class GoalDesc(C.Structure):
   """blcd_goal_desc (include/boxlcd.h)"""
   _fields_ = [('mode', C.c_int32), ('diff_delt', C.c_int32), ('n_idx', C.c_int32), ('idxs', C.c_int32 * 96),
@@ -171,6 +179,17 @@ class Handle:
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (self.n, self.n_act), actions.shape
     _check(self.lib.blcd_step(self._h, _ptr(actions), int(n_steps)))
+
+  def reset_sampled(self, idxs, seed, ops):
+    """blcd_reset_sampled: reset environments idxs (None = all) from the device-side counter-based sampler"""
+    n = self.n if idxs is None else len(idxs)
+    if idxs is not None and not hasattr(idxs, 'data_ptr'):
+      idxs = np.ascontiguousarray(idxs, dtype=np.int32)
+    arr = (SampleOp * len(ops))(*ops)
+    _check(self.lib.blcd_reset_sampled(self._h, _ptr(idxs), n, C.c_uint64(int(seed)), arr, len(ops)))
+
+  def sample_reseed(self):
+    _check(self.lib.blcd_sample_reseed(self._h))
 
   def rollout(self, actions, T, lcd_out=None, obs_out=None):
     if actions is not None and not hasattr(actions, 'data_ptr'):

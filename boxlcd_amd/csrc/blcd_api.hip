@@ -604,6 +604,10 @@ struct blcd_handle_s {
   void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
   int* dFaultAny = nullptr;  // device flag raised by step_kernel when an environment is faulted
   unsigned long long* dSchedStats = nullptr;   // blcd_sched_stats
+  int* dEpisode = nullptr;                     // blcd_reset_sampled: per-environment reset count; staging of the sampled poses / shapes
+  blcd_sample_op* dSampleOps = nullptr;
+  float* dSamplePoses = nullptr;
+  int* dSampleSel = nullptr;
   uint8_t* dLut = nullptr;   // Pillow's ellipse span table for blcd_render_poses_ex (uploaded on first use)
   int lutAmax = -1;
   int* dErr = nullptr;
@@ -1070,6 +1074,8 @@ int blcd_destroy(blcd_handle h) {
   }
   if (h->dFaultAny) (void)hipFree(h->dFaultAny);
   if (h->dSchedStats) (void)hipFree(h->dSchedStats);
+  for (void* q : {(void*)h->dEpisode, (void*)h->dSampleOps, (void*)h->dSamplePoses, (void*)h->dSampleSel})
+    if (q) (void)hipFree(q);
   if (h->dLut) (void)hipFree(h->dLut);
   if (h->dErr) (void)hipFree(h->dErr);
   if (h->st) (void)hipFree(h->st);
@@ -1118,6 +1124,116 @@ int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses
   // A full reset of a circles-only scene restarts the re-bin clock: its first chunk runs best in sampled (well mixed) order
   // (Bounce-100k 1.67e9 vs 1.51e9 when the fresh states are sorted by predicted impact first).  Scenes with polygons keep the
   // clock running, so a sort that is due happens before their first chunk (Dropbox-100k 4.4e8 -> 5.0e8).
+  if (!idxs && kCfgs[h->cfg].sh == 1) h->stepsSinceRebin = 0;
+  return BLCD_OK;
+}
+
+// ---- device-side reset sampling (include/boxlcd.h blcd_reset_sampled) ------------------------------------------------------
+__device__ inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* o0, uint32_t* o1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  *o0 = c0;
+  *o1 = c1;
+}
+constexpr int kMaxSampleOps = 160;
+__global__ void sample_kernel(const DevScene* __restrict__ S, const blcd_sample_op* __restrict__ ops, int nOps, const int* __restrict__ idxs, int n,
+                              int N, uint32_t k0, uint32_t k1, int* __restrict__ episode, float* __restrict__ poses, int* __restrict__ sel) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int e = idxs ? idxs[k] : k;
+  if (e < 0 || e >= N) return;
+  const int nb = S->nb;
+  const uint32_t epi = (uint32_t)episode[e];
+  episode[e] = (int)(epi + 1u);
+  double r[16];
+  float px[20], py[20];      // b2Vec2 position of every body placed so far (float32, as behind the SWIG boundary)
+  double ang[20];            // its angle as the reference holds it (float64)
+  for (int i = 0; i < 16; ++i) r[i] = 0.0;
+  for (int i = 0; i < nb; ++i) sel[(size_t)k * nb + i] = 0;
+  uint32_t var = 0;
+  auto uniform01 = [&]() {
+    uint32_t x0, x1;
+    philox4x32_10(k0, k1, (uint32_t)e, epi, var++, 0u, &x0, &x1);
+    return ((double)(x0 >> 5) * 67108864.0 + (double)(x1 >> 6)) * (1.0 / 9007199254740992.0);
+  };
+  for (int q = 0; q < nOps; ++q) {
+    const blcd_sample_op op = ops[q];
+    if (op.kind == 0) {
+      const double a = op.f[0] + (op.f[1] - op.f[0]) * uniform01();
+      r[op.d] = ((a + 1.0) / (2.0) * (op.f[3] - op.f[2])) + op.f[2];     // utils.py:117 mapto
+    } else if (op.kind == 1) {
+      sel[(size_t)k * nb + op.body] = uniform01() < 0.5 ? 0 : 1;
+    } else if (op.kind == 2) {
+      r[op.d] = atan2(r[op.a], r[op.b]);
+    } else if (op.kind == 3) {
+      r[op.d] = 0.0;
+    } else if (op.kind == 4) {
+      px[op.body] = (float)r[op.a];
+      py[op.body] = (float)r[op.b];
+      ang[op.body] = r[op.d];
+    } else if (op.kind == 5) {
+      double mangle = ang[op.a] + op.f[0];
+      mangle = atan2(sin(mangle), cos(mangle));
+      const double pangle = ang[op.parent];
+      const double cp = cos(pangle), sp = sin(pangle), cm = cos(mangle), sm = sin(mangle);
+      const double aax = cp * op.f[1] + -sp * op.f[2], aay = sp * op.f[1] + cp * op.f[2];
+      const double abx = cm * op.f[3] + -sm * op.f[4], aby = sm * op.f[3] + cm * op.f[4];
+      px[op.body] = (px[op.parent] + (float)aax) - (float)abx;
+      py[op.body] = (py[op.parent] + (float)aay) - (float)aby;
+      ang[op.body] = mangle;
+    }
+    if (op.kind == 4 || op.kind == 5) {
+      float* o = poses + ((size_t)k * nb + op.body) * 3;
+      o[0] = px[op.body];
+      o[1] = py[op.body];
+      o[2] = (float)ang[op.body];
+    }
+  }
+}
+
+int blcd_sample_reseed(blcd_handle h) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_sample_reseed: bad handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->dEpisode) HIPCHK(hipMemsetAsync(h->dEpisode, 0, (size_t)h->N * sizeof(int), h->stream));
+  return BLCD_OK;
+}
+
+int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t seed, const blcd_sample_op* ops, int32_t n_ops) {
+  if (!h || !ops || n < 1 || n_ops < 1 || n_ops > kMaxSampleOps) return fail(BLCD_ERR_INVALID, "blcd_reset_sampled: bad arguments");
+  if (!idxs && n != h->N) return fail(BLCD_ERR_INVALID, "blcd_reset_sampled: idxs == NULL requires n == n_envs");
+  const int nb = h->hostScene.nb;
+  for (int q = 0; q < n_ops; ++q) {
+    const blcd_sample_op& op = ops[q];
+    const bool bodyOk = op.body >= 0 && op.body < nb, regOk = op.d >= 0 && op.d < 16 && op.a >= 0 && op.b >= 0;
+    if (op.kind < 0 || op.kind > 5 || !regOk || ((op.kind == 1 || op.kind >= 4) && !bodyOk) || (op.kind <= 4 && op.kind != 1 && (op.a >= 16 || op.b >= 16)) ||
+        (op.kind == 5 && (op.parent < 0 || op.parent >= nb || op.a >= nb)))
+      return fail(BLCD_ERR_INVALID, "blcd_reset_sampled: malformed sampling program");
+  }
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->dEpisode) {
+    HIPCHK(hipMalloc((void**)&h->dEpisode, (size_t)h->N * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->dEpisode, 0, (size_t)h->N * sizeof(int), h->stream));
+    HIPCHK(hipMalloc((void**)&h->dSampleOps, kMaxSampleOps * sizeof(blcd_sample_op)));
+    HIPCHK(hipMalloc((void**)&h->dSamplePoses, (size_t)h->N * nb * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&h->dSampleSel, (size_t)h->N * nb * sizeof(int)));
+  }
+  const void* dIdx;
+  int rc;
+  if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
+  HIPCHK(hipMemcpyAsync(h->dSampleOps, ops, (size_t)n_ops * sizeof(blcd_sample_op), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(sample_kernel, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->dScene, h->dSampleOps, n_ops, (const int*)dIdx, n, h->N,
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), h->dEpisode, h->dSamplePoses, h->dSampleSel);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(reset_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, h->slotOf, (const int*)dIdx, n,
+                     (const float*)h->dSamplePoses, (const int*)h->dSampleSel);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
   if (!idxs && kCfgs[h->cfg].sh == 1) h->stepsSinceRebin = 0;
   return BLCD_OK;
 }

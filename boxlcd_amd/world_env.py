@@ -332,12 +332,17 @@ class BatchedWorldEnv(_EnvSpec):
     self.single_action_space = self.action_space
     self._device = device
     self._h = None
-    self.seed(seed)
     self.ep_t = np.zeros(self.num_envs, np.int64)
+    self.seed(seed)
 
   def seed(self, seed=0):
-    self._rng = np.random.Generator(np.random.Philox(key=int(seed)))
+    self._seed = int(seed) & 0xffffffffffffffff
+    self._episode = np.zeros(self.num_envs, np.int64)          # resets so far per environment (= the device's counters)
+    self._mirror_episode = np.zeros(self.num_envs, np.int64)   # the same for sample_initial(), the host-side mirror
+    self._sel = np.zeros((self.num_envs, len(self.scene.bodies)), np.int32)
     self._act_rng = np.random.Generator(np.random.Philox(key=int(seed) + 1))
+    if self._h is not None:
+      self._h.sample_reseed()
     return [seed]
 
   def _handle(self):
@@ -351,9 +356,107 @@ class BatchedWorldEnv(_EnvSpec):
       self._h.close()
       self._h = None
 
-  def sample_initial(self, n):
-    """(poses, shape_sel) for n envs; float64 numpy arithmetic as in the reference, vectorised (Philox stream)."""
-    return self._sample_poses(lambda lo, hi: self._rng.uniform(lo, hi, n), n, randint=lambda k, m: self._rng.integers(0, k, m))
+  # ---- initial states: a counter-based stream keyed by (seed, env id, reset count, variable) ------------------------------
+  # BASELINE.md §3 ("per-env counter-based RNG, seed = env id"): an environment's start never depends on the batch size or on
+  # which rank holds it.  The PRODUCT samples on the device (blcd_reset_sampled: reset() / reset_torch() never build poses on
+  # the host); `mirror_poses` is the numpy restatement of the same stream and the same float64 arithmetic - the checker of
+  # the device sampler and the source of explicit (poses, shape_sel) pairs for the parity tests and the bench.
+  @staticmethod
+  def _philox_u01(seed, env_ids, episodes, var):
+    """Philox4x32-10, key = seed (lo, hi), counter = (env id, reset count, var, 0) -> float64 in [0, 1) from 53 bits"""
+    M = np.uint64(0xffffffff)
+    c0 = np.asarray(env_ids, np.uint64) & M
+    c1 = np.asarray(episodes, np.uint64) & M
+    c2 = np.full_like(c0, var)
+    c3 = np.zeros_like(c0)
+    k0, k1 = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
+    for _ in range(10):
+      p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+      c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & M, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & M
+      k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return ((c0 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (c1 >> np.uint64(6)).astype(np.float64)) * (1.0 / 9007199254740992.0)
+
+  def mirror_poses(self, env_ids, episodes):
+    """(poses float32 [n, nb, 3], shape_sel int32 [n, nb]) the device sampler gives environment `env_ids[i]` at its
+    `episodes[i]`-th reset."""
+    env_ids, episodes = np.asarray(env_ids, np.int64), np.asarray(episodes, np.int64)
+    var = [0]
+
+    def u01():
+      v = var[0]
+      var[0] += 1
+      return self._philox_u01(self._seed, env_ids, episodes, v)
+    return self._sample_poses(lambda lo, hi: lo + (hi - lo) * u01(), len(env_ids), randint=lambda k, m: np.where(u01() < 0.5, 0, 1).astype(np.int32))
+
+  def sample_initial(self, n, idxs=None):
+    """Host-side mirror of what `reset(idxs)` samples on the device: (poses, shape_sel) of environments idxs (default 0..n-1) at
+    their next reset in the mirror's own count."""
+    ids = np.arange(n, dtype=np.int64) if idxs is None else np.asarray(idxs, np.int64)
+    out = self.mirror_poses(ids, self._mirror_episode[ids])
+    self._mirror_episode[ids] += 1
+    return out
+
+  def sample_program(self):
+    """The scene's sampling program for blcd_reset_sampled (include/boxlcd.h), in the reference's draw order
+    (world_env.py:197-304) - the data twin of `_sample_poses`."""
+    if getattr(self, '_prog', None) is not None:
+      return self._prog
+    from ._lib import SampleOp
+    ops = []
+    W, H, info, bodies = self.WIDTH, self.HEIGHT, self.obs_info, self.scene.bodies
+
+    def op(kind, d=0, a=0, b=0, body=0, parent=0, f=()):
+      o = SampleOp()
+      o.kind, o.d, o.a, o.b, o.body, o.parent = kind, d, a, b, body, parent
+      for i, x in enumerate(f):
+        o.f[i] = float(x)
+      ops.append(o)
+
+    def draw(d, key, lr=-1.0, ur=None):
+      ur = -lr if ur is None else ur
+      lo, hi = info[key]
+      op(0, d=d, f=(lr, ur, lo, hi))
+
+    for robot in self.world_def.robots:
+      name = robot.name + ':root'
+      rangex, rangey = 1 - (2 * robot.bound / W), 1 - (2 * robot.bound / H)
+      draw(0, name + ':x:p', -rangex, rangex)
+      draw(1, name + ':y:p', -rangey, -rangey)
+      draw(2, name + ':sin')
+      draw(3, name + ':cos')
+      op(2, d=4, a=2, b=3) if robot.rand_angle else op(3, d=4)
+      root = bodies[self.scene.body_index[name]].index
+      op(4, d=4, a=0, b=1, body=root)
+      for jname, joint in robot.joints.items():
+        link = bodies[self.scene.body_index[robot.name + ':' + jname]].index
+        parent = bodies[self.scene.body_index[robot.name + ':' + joint.parent]].index
+        op(5, a=root, body=link, parent=parent, f=(joint.angle, joint.anchorA[0], joint.anchorA[1], joint.anchorB[0], joint.anchorB[1]))
+    for obj in self.world_def.objects:
+      ob = bodies[self.scene.body_index[obj.name]].index
+      if obj.shape == 'random':
+        op(1, body=ob)
+      rangex, rangey = 1 - (2 * obj.size / W), 1 - (2 * obj.size / H)
+      draw(0, obj.name + ':x:p', -rangex, rangex)
+      draw(1, obj.name + ':y:p', -rangey, rangey if len(self.world_def.robots) == 0 else -0.25)
+      if obj.rand_angle:
+        draw(2, obj.name + ':sin')
+        draw(3, obj.name + ':cos')
+        op(2, d=4, a=2, b=3)
+      else:
+        op(3, d=4)
+      op(4, d=4, a=0, b=1, body=ob)
+    self._prog = ops
+    return ops
+
+  def _reset_on_device(self, ii):
+    """reset environments ii (int32 numpy) from the device sampler; the host only advances its copy of the reset counts and
+    recomputes the shape choices (needed by the RGB / any-size render calls)."""
+    h = self._handle()
+    h.reset_sampled(None if len(ii) == self.num_envs and (ii == np.arange(self.num_envs)).all() else ii, self._seed, self.sample_program())
+    if any(o.kind == 1 for o in self.sample_program()):
+      self._sel[ii] = self.mirror_poses(ii, self._episode[ii])[1]
+    self._episode[ii] += 1
+    self.ep_t[ii] = 0
 
   def sample_actions(self, T=None):
     shape = (self.num_envs, self.act_size) if T is None else (T, self.num_envs, self.act_size)
@@ -363,12 +466,7 @@ class BatchedWorldEnv(_EnvSpec):
     h = self._handle()
     idxs = np.arange(self.num_envs, dtype=np.int32) if idxs is None else np.asarray(idxs, dtype=np.int32)
     n = len(idxs)
-    poses, sel = self.sample_initial(n)
-    h.reset(idxs, poses, sel)
-    if getattr(self, '_sel', None) is None:
-      self._sel = np.zeros((self.num_envs, len(self.scene.bodies)), np.int32)
-    self._sel[idxs] = sel
-    self.ep_t[idxs] = 0
+    self._reset_on_device(idxs)
     if proprio is not None:
       fs = np.zeros((n, self.obs_size))
       fs[:, self.pobs_idxs] = np.asarray(proprio, dtype=np.float64)
@@ -437,12 +535,7 @@ class BatchedWorldEnv(_EnvSpec):
     tb = self._torch_bufs()
     h = self._handle()
     ii = np.arange(self.num_envs, dtype=np.int32) if idxs is None else np.asarray(torch.as_tensor(idxs).cpu() if hasattr(idxs, 'cpu') else idxs, dtype=np.int32)
-    poses, sel = self.sample_initial(len(ii))
-    h.reset(ii, poses, sel)
-    if getattr(self, '_sel', None) is None:
-      self._sel = np.zeros((self.num_envs, len(self.scene.bodies)), np.int32)
-    self._sel[ii] = sel
-    self.ep_t[ii] = 0
+    self._reset_on_device(ii)          # sampled on the device: no pose ever crosses PCIe
     tb['ep_t'][torch.as_tensor(ii.astype(np.int64), device=tb['ep_t'].device)] = 0
     return self._obs_torch()
 

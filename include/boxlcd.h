@@ -115,6 +115,27 @@ int blcd_pair_table(blcd_handle h, int32_t* pairs /* host [n_pairs][2] */);
  * idxs host; poses host|device float32 [n][n_bodies][3]; shape_sel host|device int32 [n][n_bodies] or NULL. */
 int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const int32_t* shape_sel);
 
+/* Device-side `_reset_bodies` sampling (world_env.py:197-304): reset n environments from a counter-based random stream instead
+ * of host-sampled poses, so that a training loop that resets environments never touches the host.
+ * Stream: Philox4x32-10, key = seed (lo, hi), counter = (env id, that env's reset count since blcd_sample_reseed, variable
+ * index, 0); u = ((x0 >> 5) * 2^26 + (x1 >> 6)) * 2^-53; draw = lr + (ur - lr) * u; value = mapto(draw, (lo, hi)) - all float64,
+ * the reference's expressions (utils.py:117) - so an environment's start depends on (seed, env id, reset count) only, never on
+ * the batch size or on which rank holds it.  `ops` is the scene's sampling program in the reference's draw order (the Python
+ * shim builds it from the world definition; boxlcd_amd/world_env.py mirrors it in numpy as the checker):
+ *   kind 0 DRAW   r[d] = mapto(uniform(f[0], f[1]), (f[2], f[3]))
+ *   kind 1 SEL    shape_sel[body] = uniform(0, 1) < 0.5 ? 0 : 1            ('random' object shapes)
+ *   kind 2 ATAN2  r[d] = atan2(r[a], r[b])      kind 3 ZERO r[d] = 0
+ *   kind 4 BODY   pose[body] = (float) (r[a], r[b], r[d]); remembers position (float32) and angle (float64) of `body`
+ *   kind 5 LINK   child link `body` of `parent` on the robot rooted at body `a`: f = {joint angle, anchorA.xy, anchorB.xy}
+ *                 (world_env.py:235-253: float64 angles, float32 b2Vec2 position arithmetic)
+ * idxs host|device or NULL (= all, n == n_envs). */
+typedef struct blcd_sample_op {
+  int32_t kind, d, a, b, body, parent;
+  double f[5];
+} blcd_sample_op;
+int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t seed, const blcd_sample_op* ops, int32_t n_ops);
+int blcd_sample_reseed(blcd_handle h);   /* reset counts back to 0 (env.seed()) */
+
 /* Replaces the `body.position = ...; body.angle = ...` overwrite of reset(full_state=/proprio=) (world_env.py:319-380):
  * b2Body::SetTransform semantics (velocities untouched, broad-phase proxy refreshed).  mask host uint8 [n_bodies] or NULL. */
 int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const uint8_t* mask);

@@ -275,3 +275,37 @@ def test_rollout_bits_unpacks_to_the_uint8_frames(name, n):
     h.close()
   assert outs[0][0].shape == outs[1][0].shape and (outs[0][0] == outs[1][0]).all()
   assert (outs[0][1] == outs[1][1]).all() and (outs[0][2] == outs[1][2]).all()
+
+
+@pytest.mark.parametrize('name', ['Dropbox', 'Bounce', 'Bounce2', 'Object2', 'Object3', 'Urchin', 'Luxo', 'UrchinBall', 'LuxoBall', 'UrchinCube',
+                                  'LuxoCube', 'UrchinBalls', 'LuxoBalls', 'UrchinCubes', 'LuxoCubes', 'Crab', 'CrabCube', 'SpiderCube'])
+def test_device_reset_sampler_equals_its_host_mirror(name):
+  """blcd_reset_sampled (what reset() / reset_torch() run: poses are never built on the host) against the numpy restatement of
+  the same counter-based stream and the same float64 arithmetic (BatchedWorldEnv.mirror_poses): body poses and shape choices
+  bit for bit, for a full reset, a second full reset (reset count 1) and a partial reset."""
+  n = 3000
+  env = B.BatchedWorldEnv(name, n, seed=123)
+  env.reset()
+  h = env._handle()
+  p0, s0 = env.mirror_poses(np.arange(n), np.zeros(n, np.int64))
+  assert (h.get_poses()[:, :, :3] == p0).all() and (env._sel == s0).all()
+  env.reset()
+  p1, s1 = env.mirror_poses(np.arange(n), np.ones(n, np.int64))
+  assert (h.get_poses()[:, :, :3] == p1).all() and (p1 != p0).any()
+  idxs = np.array([5, 77, 2999, 1024], np.int32)
+  env.reset(idxs)
+  got = h.get_poses()[:, :, :3]
+  p2, _ = env.mirror_poses(idxs, np.full(len(idxs), 2))
+  keep = np.setdiff1d(np.arange(n), idxs)
+  assert (got[idxs] == p2).all() and (got[keep] == p1[keep]).all()
+  # ... and the oracle started from the mirror's poses steps exactly like the device-reset batch
+  acts = env.sample_actions(5)
+  for t in range(5):
+    env.step(acts[t])
+  st = h.debug_dump()[0]
+  pm = p1.copy(); pm[idxs] = p2
+  sm = env._sel
+  sub = np.array([0, 5, 77, 1500, 2999])
+  _, _, _, ost = pyb2o.rollout(env.scene.desc, pm[sub], sm[sub], acts[:, sub], 5, threads=4)
+  assert (ost == st[sub]).all()
+  env.close()
