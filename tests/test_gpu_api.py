@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 import boxlcd_amd as B
 from boxlcd_amd._lib import Handle
+from oracle import pyb2o
 
 pytestmark = pytest.mark.gpu
 
