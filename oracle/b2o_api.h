@@ -97,6 +97,8 @@ void b2o_raster_polygon(const int32_t* xy, int32_t count, int32_t w, int32_t h, 
 void b2o_raster_ellipse(int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t w, int32_t h, uint8_t* img);
 void b2o_sincos(const float* x, int64_t n, float* s, float* c);
 void b2o_mass_data(const b2o_scene_desc* scene, int32_t shape, float density, float* out /* mass cx cy I n v.. */);
+/* narrow phase by itself (tests/test_oracle_narrowphase.py): shape spec {kind, params..}, pose {x, y, angle}; out float[24], returns pointCount */
+int32_t b2o_collide(const float* specA, const float* poseA, const float* specB, const float* poseB, float* out);
 
 /* CPU-baseline rollout: n envs x T env-steps, envs statically partitioned over `threads`; returns seconds.
  * poses [n][nb][3], shape_sel [n][nb], actions [T][n][n_act] (may be NULL -> zeros); outputs (may be NULL):

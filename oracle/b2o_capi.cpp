@@ -411,6 +411,62 @@ void b2o_mass_data(const b2o_scene_desc* scene, int32_t shape, float density, fl
   }
 }
 
+// Narrow phase by itself, for tests/test_oracle_narrowphase.py (geometry-based properties of the manifolds: an algorithmic check
+// that does not depend on this restatement being compared with a copy of itself).  Shape = {kind 0 circle r | 1 box hx hy | 2 edge
+// x1 y1 x2 y2 | 3 polygon n x0 y0 ...}, pose = {x, y, angle}; dispatch as b2Contact's s_registers (A = the lower shape type).
+// out = {pointCount, type, localNormal.xy, localPoint.xy, [lp.xy, id.key] x2, world normal.xy, [world point.xy, separation] x2, swapped}
+static Shape ShapeFromSpec(const float* sp) {
+  Shape s;
+  int kind = (int)sp[0];
+  if (kind == 0) ShapeSetCircle(&s, sp[1]);
+  else if (kind == 1) ShapeSetAsBox(&s, sp[1], sp[2]);
+  else if (kind == 2) ShapeSetEdge(&s, V2(sp[1], sp[2]), V2(sp[3], sp[4]));
+  else {
+    Vec2 vs[16];
+    int n = (int)sp[1];
+    for (int i = 0; i < n && i < 16; ++i) vs[i] = V2(sp[2 + 2 * i], sp[3 + 2 * i]);
+    ShapeSetPolygon(&s, vs, n);
+  }
+  return s;
+}
+int32_t b2o_collide(const float* specA, const float* poseA, const float* specB, const float* poseB, float* out) {
+  Shape a = ShapeFromSpec(specA), b = ShapeFromSpec(specB);
+  Transform xa, xb;
+  xa.p = V2(poseA[0], poseA[1]); xa.q.Set(poseA[2]);
+  xb.p = V2(poseB[0], poseB[1]); xb.q.Set(poseB[2]);
+  // b2Contact::s_registers: the fixture with the "smaller" collision routine row comes first; (edge, circle), (edge, polygon),
+  // (polygon, circle) keep the non-circle / edge shape as A
+  int swapped = 0;
+  auto rank = [](const Shape& s) { return s.type == kEdge ? 0 : (s.type == kPolygon ? 1 : 2); };
+  if (rank(a) > rank(b)) { std::swap(a, b); std::swap(xa, xb); swapped = 1; }
+  Manifold m;
+  m.pointCount = 0;
+  m.type = 0;
+  if (a.type == kCircle && b.type == kCircle) CollideCircles(&m, &a, xa, &b, xb);
+  else if (a.type == kPolygon && b.type == kCircle) CollidePolygonAndCircle(&m, &a, xa, &b, xb);
+  else if (a.type == kPolygon && b.type == kPolygon) CollidePolygons(&m, &a, xa, &b, xb);
+  else if (a.type == kEdge && b.type == kCircle) CollideEdgeAndCircle(&m, &a, xa, &b, xb);
+  else if (a.type == kEdge && b.type == kPolygon) CollideEdgeAndPolygon(&m, &a, xa, &b, xb);
+  else return -1;
+  for (int i = 0; i < 24; ++i) out[i] = 0.0f;
+  out[0] = (float)m.pointCount;
+  out[1] = (float)m.type;
+  out[2] = m.localNormal.x; out[3] = m.localNormal.y; out[4] = m.localPoint.x; out[5] = m.localPoint.y;
+  for (int j = 0; j < m.pointCount && j < 2; ++j) {
+    out[6 + 3 * j] = m.points[j].localPoint.x; out[7 + 3 * j] = m.points[j].localPoint.y; out[8 + 3 * j] = (float)m.points[j].id.key;
+  }
+  if (m.pointCount > 0) {
+    WorldManifold wm;
+    wm.Initialize(&m, xa, a.radius, xb, b.radius);
+    out[12] = wm.normal.x; out[13] = wm.normal.y;
+    for (int j = 0; j < m.pointCount && j < 2; ++j) {
+      out[14 + 3 * j] = wm.points[j].x; out[15 + 3 * j] = wm.points[j].y; out[16 + 3 * j] = wm.separations[j];
+    }
+  }
+  out[20] = (float)swapped;
+  return m.pointCount;
+}
+
 double b2o_rollout(const b2o_scene_desc* scene, int32_t n, int32_t T, int32_t threads, const float* poses,
                    const int32_t* shape_sel, const float* actions, float* obs_out, uint8_t* lcd_out, float* state_out,
                    int32_t render_every_step) {
