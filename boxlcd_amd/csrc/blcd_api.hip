@@ -563,6 +563,7 @@ struct blcd_handle_s {
   uint8_t* keys = nullptr;
   int *binCounts = nullptr, *binOffsets = nullptr;
   int rebinEvery = 0;       // 0 = never; k = after every k-th env step
+  static constexpr int kMaxCohortsDecl = 4;
   int lanes = 64;           // environments per wave in step_kernel (BLCD_LANES)
   // environment-level scheduling of fused chunks (joint-free classes): passes per chunk (1 = off) and the most
   // lanes of a wave that may still be sweeping for those lanes to be suspended (BLCD_YIELD_PASSES, BLCD_YIELD_LANES)
@@ -574,6 +575,10 @@ struct blcd_handle_s {
   // in-wave batching (BLCD_WAVE_BATCH=<lanes>): the plain chunked rollout on the scheduler's kernel - a suspended lane resumes
   // inside the same launch, together with the other lanes of its wave that are owed the same kind of work
   int waveBatch = 0;
+  // two wave widths per launch for re-binned batches (BLCD_TWO_WIDTHS=0 turns it off): the awake slots in narrower waves once they
+  // no longer fill the SIMDs; sortedBlocks[c] = blocks of cohort c's last slot sort (0 = the current order is not a sorted one)
+  int twoWidths = 16, nSimds = 0;
+  int sortedBlocks[kMaxCohortsDecl] = {0, 0, 0, 0};
   // goal epilogue (blcd_goal_*): device-resident goals, previous deltas and scratch observation buffers
   blcd_goal_desc goal{};
   bool goalSet = false;
@@ -711,6 +716,15 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
   hipStream_t stream = cohort > 0 ? h->cstream[cohort] : h->stream;
   dim3 grid((n + lanes - 1) / lanes), block(kBlock);
+  // two wave widths (see step_kernel): only for the plain kernel on a slot order that the last sort produced for exactly this range
+  const int* heavyEnd = nullptr;
+  const int cIdx = cohort < 0 ? 0 : cohort;
+  if (h->twoWidths && nEnvSteps > 0 && nPasses == 1 && stepBudget == 0 && h->waveBatch == 0 && lanes == 64 && !h->waveTimes &&
+      (cohort >= 0 || h->nCohorts == 1) && h->sortedBlocks[cIdx] > 0) {
+    const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;
+    heavyEnd = h->binOffsets + (size_t)cIdx * nBlocksAll * kBins + (size_t)(kBins - 1) * h->sortedBlocks[cIdx];   // start of the asleep bin
+    grid = dim3(h->nSimds + 2 + (n + 63) / 64);   // heavy blocks <= max(nSimds, heavy / 64) + 1, light blocks <= light / 64 + 1
+  }
   if (cohort < 0) {
     if (!e0) {
       e0 = h->ev0;
@@ -720,7 +734,8 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   }
   StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
              pass, (pass + 1 < nPasses || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits,
-             (nPasses > 1 || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? 1 : 0, stepBudget, stepBudget > 0 || nPasses > 1 ? 0 : h->waveBatch};
+             (nPasses > 1 || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? 1 : 0, stepBudget, heavyEnd, h->nSimds | (h->twoWidths << 16),
+             stepBudget > 0 || nPasses > 1 ? 0 : h->waveBatch};
   int idx = 0;
 #define X(a, b, c, d) \
   if (h->cfg == idx) launch_step_##a##_##b##_##c##_##d(grid, stream, A); \
@@ -759,6 +774,7 @@ static int launch_rebin(blcd_handle h, bool midChunk = false, int tEnd = 0) {
     const int nBlocks = (n + kRebinBlock - 1) / kRebinBlock;
     int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
     int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
+    h->sortedBlocks[c] = midChunk ? 0 : nBlocks;
     hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->dScene, h->st + lo, h->N, n, h->keys + lo, counts,
                        midChunk && h->rebinEvery <= 0 ? -1 : h->binMode, tEnd);
     hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, offsets, nBlocks * kBins);
@@ -983,6 +999,15 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     const int simds = prop.multiProcessorCount * 4;
+    h->nSimds = simds;
+    // narrowest wave of the awake region (0 = one width).  Measured (tools/tw_bench.sh): Object2-200k +6 %, Bounce2-100k +9 %,
+    // Object3-100k +12 % at 16; the one-body classes lose (Bounce-100k -4 %, Dropbox-100k -1 %: narrow waves give up the
+    // wave-coalesced frame store and the sharing of impact steps that the impact-time sort sets up) and keep one width
+    h->twoWidths = h->hostScene.nb >= 2 ? 16 : 0;
+    if (const char* ev = getenv("BLCD_TWO_WIDTHS")) {
+      int q = atoi(ev);
+      h->twoWidths = q <= 0 ? 0 : (q == 1 ? 16 : (q > 64 ? 64 : q));
+    }
     if (simds > 0 && (long long)n_envs < 64LL * simds) {
       int l = (n_envs + simds - 1) / simds;
       h->lanes = l < 16 ? 16 : (l > 64 ? 64 : l);   // below ~16 lanes the scratch footprint per useful lane costs more than the narrower union saves (Urchin-4096: 76 / 66 / 97 ms at 64 / 16 / 4 lanes)
@@ -1121,6 +1146,7 @@ int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses
                      (const float*)dPoses, (const int*)dSel);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
+  for (int& b : h->sortedBlocks) b = 0;   // reset environments are awake wherever their slot is: the order is no longer a sorted one
   // A full reset of a circles-only scene restarts the re-bin clock: its first chunk runs best in sampled (well mixed) order
   // (Bounce-100k 1.67e9 vs 1.51e9 when the fresh states are sorted by predicted impact first).  Scenes with polygons keep the
   // clock running, so a sort that is due happens before their first chunk (Dropbox-100k 4.4e8 -> 5.0e8).
@@ -1234,6 +1260,7 @@ int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t s
                      (const float*)h->dSamplePoses, (const int*)h->dSampleSel);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
+  for (int& b : h->sortedBlocks) b = 0;   // reset environments are awake wherever their slot is: the order is no longer a sorted one
   if (!idxs && kCfgs[h->cfg].sh == 1) h->stepsSinceRebin = 0;
   return BLCD_OK;
 }
@@ -1690,6 +1717,7 @@ int blcd_set_state(blcd_handle h, const void* blob, size_t size) {
   hipLaunchKernelGGL(invert_kernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, h->N);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
+  for (int& b : h->sortedBlocks) b = 0;
   return BLCD_OK;
 }
 

@@ -24,14 +24,36 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       int nEnvSteps, int nWorldSteps, int setMotors, int lanes,
                                                       unsigned long long* __restrict__ waveTimes, long long actStride,
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
-                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits, int stepBudget, int resumeBatch) {
+                                                      int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits, int stepBudget, int resumeBatch, const int* __restrict__ heavyEnd, int nSimds) {
   uint32_t* const ldsRows = Env<NB, NJ, NP, SH, SCHED>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
   unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
   // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
-  if ((int)threadIdx.x >= lanes) return;
-  int slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
-  if (slot >= nSlots) return;
+  int slot;
+  if (heavyEnd) {
+    // Two wave widths in one launch (re-binned batches).  The slot sort puts the environments that are not asleep first
+    // (*heavyEnd of them, heaviest first).  While they oversubscribe the SIMDs, full waves are best (total wave time counts); once
+    // most of the batch sleeps, the launch lasts as long as ONE awake wave's dependent chain while most SIMDs idle - then the
+    // awake environments are spread over all SIMDs in narrower waves, whose union of code paths (who hits a wall this step,
+    // who needs the TOI sub-step) is smaller.  Placement only.  The sleeping tail keeps full waves (coalesced frame stores).
+    int he = *heavyEnd;
+    he = he < 0 ? 0 : (he > nSlots ? nSlots : he);
+    const int wmin = nSimds >> 16, ns = nSimds & 0xffff;   // narrowest width in the high half
+    const int wh = he >= 64 * ns ? 64 : (he <= wmin * ns ? wmin : (he + ns - 1) / ns);
+    const int heavyBlocks = (he + wh - 1) / wh;
+    if ((int)blockIdx.x < heavyBlocks) {
+      if ((int)threadIdx.x >= wh) return;
+      slot = blockIdx.x * wh + threadIdx.x;
+      if (slot >= he) return;
+    } else {
+      slot = he + ((int)blockIdx.x - heavyBlocks) * 64 + threadIdx.x;
+      if (slot >= nSlots) return;
+    }
+  } else {
+    if ((int)threadIdx.x >= lanes) return;
+    slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
+    if (slot >= nSlots) return;
+  }
   const int e = eid[slot];
   using EnvT = Env<NB, NJ, NP, SH, SCHED>;
   if constexpr (!SCHED) {
@@ -322,12 +344,12 @@ void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipS
   if constexpr (BLCD_NB <= 7) {
     if (A.sched) {
       hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, true>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                         A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget, A.resumeBatch);
+                         A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget, A.resumeBatch, A.heavyEnd, A.nSimds);
       return;
     }
   }
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, false>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
-                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget, A.resumeBatch);
+                     A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget, A.resumeBatch, A.heavyEnd, A.nSimds);
 }
 void BLCD_NAME(launch_set_poses_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const SetPosesArgs& A) {
   hipLaunchKernelGGL((set_poses_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH>), grid, dim3(64), 0, stream, A.S, A.st, A.N, A.slotOf, A.idxs, A.n,

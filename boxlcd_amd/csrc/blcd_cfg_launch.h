@@ -32,6 +32,8 @@ struct StepArgs {
   int lcdBits;        // lcdOut holds frames at one bit per pixel (blcd_rollout_bits)
   int sched;          // launch the scheduler's kernel (step_kernel<..., true>): passes / suspension / resumption
   int stepBudget;     // scheduler kernel: world steps an environment may advance in this launch (0 = to the end)
+  const int* heavyEnd;  // device: number of leading slots that are not asleep after the last slot sort (null = one wave width, `lanes`)
+  int nSimds;           // SIMDs of the device (wave-width choice for the awake slots)
   int resumeBatch;    // scheduler kernel: > 0 = suspended lanes resume inside the launch, as soon as this many of the wave wait for the same kind of work
 };
 struct SetPosesArgs {

@@ -419,3 +419,28 @@ def test_asynchronous_rollouts_change_nothing(monkeypatch, name, n):
   idx = np.random.RandomState(2).choice(n, 48, replace=False)
   _, _, olcd, ost = pyb2o.rollout(d, poses[idx], sel[idx], acts[:, idx], T, threads=8)
   assert (olcd == res[1][0][-1][idx]).all()
+
+
+@pytest.mark.parametrize('name,n', [('Bounce', 70_000), ('Dropbox', 70_000), ('Object2', 90_000)])
+def test_two_wave_widths_change_nothing(monkeypatch, name, n):
+  """Re-binned batches: once the environments that are not asleep no longer fill the SIMDs they are stepped in narrower waves (the
+  sleeping tail keeps full waves) - a launch then holds waves of two widths.  Placement only: frames, observations and the final
+  state equal the one-width run."""
+  T = 100
+  env, poses, sel = parity.make_batch(name, n, 13)
+  d = env.scene.desc
+  res = []
+  for tw in ('0', '16'):
+    monkeypatch.setenv('BLCD_TWO_WIDTHS', tw)
+    h = Handle(d, n, 0)
+    h.reset(None, poses, sel)
+    lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+    obs = np.zeros((T, n, d.n_obs), np.float32)
+    h.rollout(None, T, lcd, obs)
+    h.rollout(None, 20)
+    res.append((lcd, obs, [x.copy() for x in h.debug_dump()]))
+    assert not h.faults().any()
+    h.close()
+  assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+  for x, y in zip(res[0][2], res[1][2]):
+    assert (x == y).all()
