@@ -943,6 +943,10 @@ static void release_stream(int, hipStream_t) {}
 
 int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, blcd_handle* out) {
   if (!scene || !out || n_envs < 1) return fail(BLCD_ERR_INVALID, "blcd_create: bad arguments");
+#ifndef BLCD_WAVETIMES
+  // the per-wave timers are compiled out of the product kernels (they cost every class ~20 registers): diagnostic builds only
+  if (getenv("BLCD_WAVETIMES")) return fail(BLCD_ERR_UNSUPPORTED, "BLCD_WAVETIMES needs a library built with BLCD_DEFS=-DBLCD_WAVETIMES");
+#endif
   int ndev = blcd_device_count();
   if (ndev <= 0) return fail(BLCD_ERR_NO_DEVICE, "no HIP device available (boxlcd_hip has no CPU path)");
   if (device < 0 || device >= ndev) return fail(BLCD_ERR_NO_DEVICE, "device index out of range");
@@ -986,7 +990,9 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   if (const char* ev = getenv("BLCD_BINMODE")) h->binMode = atoi(ev);
+#ifdef BLCD_WAVETIMES
   if (getenv("BLCD_WAVETIMES")) HIPCHK(hipMalloc((void**)&h->waveTimes, (size_t)n_envs * 9 * sizeof(unsigned long long)));
+#endif
   if (const char* ev = getenv("BLCD_CHUNK")) {
     h->rolloutChunk = atoi(ev);
     h->chunkFixed = true;
@@ -1764,7 +1770,7 @@ int blcd_sched_stats(blcd_handle h, uint64_t* out8) {
 
 int blcd_debug_wave_times(blcd_handle h, uint64_t* out, int32_t cap) {
   if (!h || !out) return fail(BLCD_ERR_INVALID, "blcd_debug_wave_times: bad arguments");
-  if (!h->waveTimes) return fail(BLCD_ERR_UNSUPPORTED, "set BLCD_WAVETIMES=1 before blcd_create");
+  if (!h->waveTimes) return fail(BLCD_ERR_UNSUPPORTED, "build with BLCD_DEFS=-DBLCD_WAVETIMES and set BLCD_WAVETIMES=1 before blcd_create");
   int nw = (h->N + h->lanes - 1) / h->lanes;
   if (nw * 9 > cap) nw = cap / 9;
   HIPCHK(hipSetDevice(h->device));

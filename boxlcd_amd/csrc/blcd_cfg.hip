@@ -18,6 +18,14 @@
 
 namespace blcd {
 
+// Per-wave timers / event counters (blcd_debug_wave_times) are a BUILD-time feature (BLCD_DEFS=-DBLCD_WAVETIMES): as a run-time
+// switch they kept 16 counter registers and their updates alive in every product kernel.
+#ifdef BLCD_WAVETIMES
+constexpr bool kWaveTimes = true;
+#else
+constexpr bool kWaveTimes = false;
+#endif
+
 template <int NB, int NJ, int NP, int SH, bool SCHED>
 __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const DevScene* __restrict__ S, float* __restrict__ st, int N, int nSlots,
                                                       const int* __restrict__ eid, const float* __restrict__ actions,
@@ -26,7 +34,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
                                                       uint8_t* __restrict__ lcdOut, float* __restrict__ obsOut, int* __restrict__ faultAny,
                                                       int pass, int yieldMaxLanes, unsigned long long* __restrict__ schedStats, int lcdBits, int stepBudget, int resumeBatch, const int* __restrict__ heavyEnd, int nSimds) {
   uint32_t* const ldsRows = Env<NB, NJ, NP, SH, SCHED>::ldsFrameRows();   // LCD row masks of the wave's 64 environments (stride 17: conflict-free); shares LDS with the staged island's contact block
-  unsigned long long t0 = waveTimes ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic only (BLCD_WAVETIMES)
+  unsigned long long t0 = (kWaveTimes && waveTimes) ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic builds only (BLCD_WAVETIMES)
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
   // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
   int slot;
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     // ---- the plain kernel: every lane runs its environment through the whole launch in lock step ----
     EnvT env;
     env.load(S, st, N, slot);
-    env.profOn = waveTimes != nullptr;
+    env.profOn = kWaveTimes && waveTimes != nullptr;
 #ifdef BLCD_ABLATION
     if (S->dbgSkip & 8) nEnvSteps = nWorldSteps = 0;
 #endif
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
     env.checkFault();
     if (env.fault && faultAny) *faultAny = 1;
     env.store(st, N, slot);
-    if (waveTimes) {
+    if (kWaveTimes && waveTimes) {
       // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
       unsigned long long* o = waveTimes + (size_t)blockIdx.x * 9;
       if (threadIdx.x == 0) o[0] = __builtin_amdgcn_s_memrealtime() - t0;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   const bool fullWave = __ballot(1) == ~0ull;    // every lane of the wave holds an environment (the coalesced frame store needs all 64)
   EnvT env;
   env.load(S, st, N, slot);
-  env.profOn = waveTimes != nullptr;
+  env.profOn = kWaveTimes && waveTimes != nullptr;
   env.toiPending = (prog >> 18) & 1u;
   env.velMask = prog1 & 0x7fu;
   env.posMask = (prog1 >> 7) & 0x7fu;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   env.checkFault();
   if (env.fault && faultAny) *faultAny = 1;
   env.store(st, N, slot);
-  if (waveTimes) {
+  if (kWaveTimes && waveTimes) {
     // wave total in 100 MHz ticks + per-phase shader cycles / event counts (lane maxima via cross-lane max)
     unsigned long long* o = waveTimes + (size_t)blockIdx.x * 9;
     if (threadIdx.x == 0) o[0] = __builtin_amdgcn_s_memrealtime() - t0;

@@ -1,5 +1,5 @@
 // blcd_collide.h — shapes + narrow phase of the HIP product (host+device): b2PolygonShape::Set/SetAsBox/ComputeMass,
-// b2CollideCircles, b2CollidePolygonAndCircle, b2CollidePolygons, b2CollideEdgeAndCircle, b2CollideEdgeAndPolygon
+// b2CollideCircles, b2CollidePolygonAndCircle, b2CollidePolygons; the two edge routines are blcd_collide_wall.h
 // (Box2D 2.3.x semantics).  Shapes come from boxLCD/world_env.py:273,311-314 and
 // boxLCD/world_defs.py:82-83,103-108.
 #pragma once
@@ -624,69 +624,7 @@ BLCD_HD static inline void CollidePolygons(Manifold* manifold, const Shape* poly
   manifold->pointCount = pointCount;
 }
 
-// b2CollideEdgeAndCircle (b2CollideEdge.cpp) — isolated edge (m_hasVertex0 = m_hasVertex3 = false)
-BLCD_HD static inline void CollideEdgeAndCircle(Manifold* manifold, const Shape* edgeA, const Transform& xfA, const Shape* circleB,
-                                        const Transform& xfB) {
-  manifold->pointCount = 0;
-  Vec2 Q = MulT(xfA, Mul(xfB, circleB->v[0]));
-  Vec2 A = edgeA->v[0], B = edgeA->v[1];
-  Vec2 e = B - A;
-  float u = Dot(e, B - Q);
-  float v = Dot(e, Q - A);
-  float radius = edgeA->radius + circleB->radius;
-  ContactFeature cf;
-  cf.indexB = 0;
-  cf.typeB = kFeatureVertex;
-  if (v <= 0.0f) {
-    Vec2 P = A;
-    Vec2 d = Q - P;
-    float dd = Dot(d, d);
-    if (dd > radius * radius) return;
-    cf.indexA = 0;
-    cf.typeA = kFeatureVertex;
-    manifold->pointCount = 1;
-    manifold->type = kManifoldCircles;
-    manifold->localNormal = V2(0.0f, 0.0f);
-    manifold->localPoint = P;
-    manifold->points[0].id.key = 0;
-    manifold->points[0].id.cf = cf;
-    manifold->points[0].localPoint = circleB->v[0];
-    return;
-  }
-  if (u <= 0.0f) {
-    Vec2 P = B;
-    Vec2 d = Q - P;
-    float dd = Dot(d, d);
-    if (dd > radius * radius) return;
-    cf.indexA = 1;
-    cf.typeA = kFeatureVertex;
-    manifold->pointCount = 1;
-    manifold->type = kManifoldCircles;
-    manifold->localNormal = V2(0.0f, 0.0f);
-    manifold->localPoint = P;
-    manifold->points[0].id.key = 0;
-    manifold->points[0].id.cf = cf;
-    manifold->points[0].localPoint = circleB->v[0];
-    return;
-  }
-  float den = Dot(e, e);
-  Vec2 P = (1.0f / den) * (u * A + v * B);
-  Vec2 d = Q - P;
-  float dd = Dot(d, d);
-  if (dd > radius * radius) return;
-  Vec2 n = V2(-e.y, e.x);
-  if (Dot(n, Q - A) < 0.0f) n = V2(-n.x, -n.y);
-  Normalize(n);
-  cf.indexA = 0;
-  cf.typeA = kFeatureFace;
-  manifold->pointCount = 1;
-  manifold->type = kManifoldFaceA;
-  manifold->localNormal = n;
-  manifold->localPoint = A;
-  manifold->points[0].id.key = 0;
-  manifold->points[0].id.cf = cf;
-  manifold->points[0].localPoint = circleB->v[0];
-}
+// (wall, circle) and (wall, polygon) - b2CollideEdgeAndCircle, b2EPCollider - live in blcd_collide_wall.h
 
 // pv[idx] for a run-time idx as a compare/select chain (keeps the array in registers)
 template <size_t... I>
@@ -697,218 +635,6 @@ BLCD_HD static inline Vec2 SelVecImpl(const Vec2 (&a)[kShapeVerts], int idx, std
 }
 BLCD_HD static inline Vec2 SelVec(const Vec2 (&a)[kShapeVerts], int idx) {
   return SelVecImpl(a, idx, std::make_index_sequence<kShapeVerts - 1>{});
-}
-
-// b2EPCollider::Collide (b2CollideEdge.cpp) — isolated edge
-BLCD_HD static inline void CollideEdgeAndPolygon(Manifold* manifold, const Shape* edgeA, const Transform& xfA, const Shape* polygonB,
-                                         const Transform& xfB) {
-  enum { kUnknown = 0, kEdgeA = 1, kEdgeB = 2 };
-  struct EPAxis {
-    int type;
-    int index;
-    float separation;
-  };
-  Transform m_xf = MulT(xfA, xfB);
-  Vec2 m_centroidB = Mul(m_xf, polygonB->centroid);
-  Vec2 m_v1 = edgeA->v[0];
-  Vec2 m_v2 = edgeA->v[1];
-  Vec2 edge1 = m_v2 - m_v1;
-  Normalize(edge1);
-  Vec2 m_normal1 = V2(edge1.y, -edge1.x);
-  float offset1 = Dot(m_normal1, m_centroidB - m_v1);
-  bool m_front = offset1 >= 0.0f;
-  Vec2 m_normal, m_lowerLimit, m_upperLimit;
-  if (m_front) {
-    m_normal = m_normal1;
-    m_lowerLimit = -m_normal1;
-    m_upperLimit = -m_normal1;
-  } else {
-    m_normal = -m_normal1;
-    m_lowerLimit = m_normal1;
-    m_upperLimit = m_normal1;
-  }
-  // polygonB in frame A
-  Vec2 pv[kShapeVerts], pn[kShapeVerts];
-  int pcount = polygonB->count;
-#pragma unroll
-  for (int i = 0; i < kShapeVerts; ++i) {
-    if (i < pcount) {
-      pv[i] = Mul(m_xf, polygonB->v[i]);
-      pn[i] = Mul(m_xf.q, polygonB->n[i]);
-    } else {
-      pv[i] = V2(0.0f, 0.0f);
-      pn[i] = V2(0.0f, 0.0f);
-    }
-  }
-  float m_radius = 2.0f * kPolygonRadius;
-  manifold->pointCount = 0;
-
-  // ComputeEdgeSeparation
-  EPAxis edgeAxis;
-  edgeAxis.type = kEdgeA;
-  edgeAxis.index = m_front ? 0 : 1;
-  edgeAxis.separation = FLT_MAX;
-#pragma unroll
-  for (int i = 0; i < kShapeVerts; ++i) {
-    if (i < pcount) {
-      float s = Dot(m_normal, pv[i] - m_v1);
-      if (s < edgeAxis.separation) edgeAxis.separation = s;
-    }
-  }
-  if (edgeAxis.type == kUnknown) return;
-  if (edgeAxis.separation > m_radius) return;
-
-  // ComputePolygonSeparation
-  EPAxis polygonAxis;
-  polygonAxis.type = kUnknown;
-  polygonAxis.index = -1;
-  polygonAxis.separation = -FLT_MAX;
-  {
-    Vec2 perp = V2(-m_normal.y, m_normal.x);
-    bool stop = false;
-#pragma unroll
-    for (int i = 0; i < kShapeVerts; ++i) {
-      if (i >= pcount || stop) continue;
-      Vec2 n = -pn[i];
-      float s1 = Dot(n, pv[i] - m_v1);
-      float s2 = Dot(n, pv[i] - m_v2);
-      float s = Min(s1, s2);
-      if (s > m_radius) {
-        polygonAxis.type = kEdgeB;
-        polygonAxis.index = i;
-        polygonAxis.separation = s;
-        stop = true;
-        continue;
-      }
-      if (Dot(n, perp) >= 0.0f) {
-        if (Dot(n - m_upperLimit, m_normal) < -kAngularSlop) continue;
-      } else {
-        if (Dot(n - m_lowerLimit, m_normal) < -kAngularSlop) continue;
-      }
-      if (s > polygonAxis.separation) {
-        polygonAxis.type = kEdgeB;
-        polygonAxis.index = i;
-        polygonAxis.separation = s;
-      }
-    }
-  }
-  if (polygonAxis.type != kUnknown && polygonAxis.separation > m_radius) return;
-
-  const float k_relativeTol = 0.98f;
-  const float k_absoluteTol = 0.001f;
-  EPAxis primaryAxis;
-  if (polygonAxis.type == kUnknown) {
-    primaryAxis = edgeAxis;
-  } else if (polygonAxis.separation > k_relativeTol * edgeAxis.separation + k_absoluteTol) {
-    primaryAxis = polygonAxis;
-  } else {
-    primaryAxis = edgeAxis;
-  }
-
-  ClipVertex ie[2];
-  struct {
-    int i1, i2;
-    Vec2 v1, v2, normal, sideNormal1, sideNormal2;
-    float sideOffset1, sideOffset2;
-  } rf;
-  if (primaryAxis.type == kEdgeA) {
-    manifold->type = kManifoldFaceA;
-    int bestIndex = 0;
-    float bestValue = Dot(m_normal, pn[0]);
-#pragma unroll
-    for (int i = 1; i < kShapeVerts; ++i) {
-      if (i < pcount) {
-        float value = Dot(m_normal, pn[i]);
-        if (value < bestValue) {
-          bestValue = value;
-          bestIndex = i;
-        }
-      }
-    }
-    int i1 = bestIndex;
-    int i2 = i1 + 1 < pcount ? i1 + 1 : 0;
-    ie[0].v = SelVec(pv, i1);
-    ie[0].id.cf.indexA = 0;
-    ie[0].id.cf.indexB = (uint8_t)i1;
-    ie[0].id.cf.typeA = kFeatureFace;
-    ie[0].id.cf.typeB = kFeatureVertex;
-    ie[1].v = SelVec(pv, i2);
-    ie[1].id.cf.indexA = 0;
-    ie[1].id.cf.indexB = (uint8_t)i2;
-    ie[1].id.cf.typeA = kFeatureFace;
-    ie[1].id.cf.typeB = kFeatureVertex;
-    if (m_front) {
-      rf.i1 = 0;
-      rf.i2 = 1;
-      rf.v1 = m_v1;
-      rf.v2 = m_v2;
-      rf.normal = m_normal1;
-    } else {
-      rf.i1 = 1;
-      rf.i2 = 0;
-      rf.v1 = m_v2;
-      rf.v2 = m_v1;
-      rf.normal = -m_normal1;
-    }
-  } else {
-    manifold->type = kManifoldFaceB;
-    ie[0].v = m_v1;
-    ie[0].id.cf.indexA = 0;
-    ie[0].id.cf.indexB = (uint8_t)primaryAxis.index;
-    ie[0].id.cf.typeA = kFeatureVertex;
-    ie[0].id.cf.typeB = kFeatureFace;
-    ie[1].v = m_v2;
-    ie[1].id.cf.indexA = 0;
-    ie[1].id.cf.indexB = (uint8_t)primaryAxis.index;
-    ie[1].id.cf.typeA = kFeatureVertex;
-    ie[1].id.cf.typeB = kFeatureFace;
-    rf.i1 = primaryAxis.index;
-    rf.i2 = rf.i1 + 1 < pcount ? rf.i1 + 1 : 0;
-    rf.v1 = SelVec(pv, rf.i1);
-    rf.v2 = SelVec(pv, rf.i2);
-    rf.normal = SelVec(pn, rf.i1);
-  }
-  rf.sideNormal1 = V2(rf.normal.y, -rf.normal.x);
-  rf.sideNormal2 = -rf.sideNormal1;
-  rf.sideOffset1 = Dot(rf.sideNormal1, rf.v1);
-  rf.sideOffset2 = Dot(rf.sideNormal2, rf.v2);
-  ClipVertex clipPoints1[2];
-  ClipVertex clipPoints2[2];
-  int np;
-  np = ClipSegmentToLine(clipPoints1, ie, rf.sideNormal1, rf.sideOffset1, rf.i1);
-  if (np < kMaxManifoldPoints) return;
-  np = ClipSegmentToLine(clipPoints2, clipPoints1, rf.sideNormal2, rf.sideOffset2, rf.i2);
-  if (np < kMaxManifoldPoints) return;
-  if (primaryAxis.type == kEdgeA) {
-    manifold->localNormal = rf.normal;
-    manifold->localPoint = rf.v1;
-  } else {
-    manifold->localNormal = polygonB->n[rf.i1];
-    manifold->localPoint = polygonB->v[rf.i1];
-  }
-  int pointCount = 0;
-#pragma unroll
-  for (int i = 0; i < kMaxManifoldPoints; ++i) {
-    float separation = Dot(rf.normal, clipPoints2[i].v - rf.v1);
-    if (separation <= m_radius) {
-      ManifoldPoint cp;
-      cp.normalImpulse = 0.0f;
-      cp.tangentImpulse = 0.0f;
-      if (primaryAxis.type == kEdgeA) {
-        cp.localPoint = MulT(m_xf, clipPoints2[i].v);
-        cp.id = clipPoints2[i].id;
-      } else {
-        cp.localPoint = clipPoints2[i].v;
-        cp.id.cf.typeA = clipPoints2[i].id.cf.typeB;
-        cp.id.cf.typeB = clipPoints2[i].id.cf.typeA;
-        cp.id.cf.indexA = clipPoints2[i].id.cf.indexB;
-        cp.id.cf.indexB = clipPoints2[i].id.cf.indexA;
-      }
-      PutManifoldPoint(manifold, pointCount, cp);
-      ++pointCount;
-    }
-  }
-  manifold->pointCount = pointCount;
 }
 
 }  // namespace blcd

@@ -239,13 +239,14 @@ struct RegIsland {
     Mat22 nm, K;
     float friction;
   };
+  template <bool WALLA = false>   // WALLA: the caller never reads rA (see sweepContact)
   __device__ __forceinline__ SweepC loadSweepC(int k, const RContact& c_) const {
     SweepC q;
     if constexpr (CLDS) {
       const float* p = C + 64 * kCtWords * k;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        q.rA[j] = V2(p[64 * (7 * j)], p[64 * (7 * j + 1)]);
+        q.rA[j] = WALLA ? V2(0.0f, 0.0f) : V2(p[64 * (7 * j)], p[64 * (7 * j + 1)]);
         q.rB[j] = V2(p[64 * (7 * j + 2)], p[64 * (7 * j + 3)]);
         q.normalMass[j] = p[64 * (7 * j + 4)];
         q.tangentMass[j] = p[64 * (7 * j + 5)];
@@ -373,12 +374,22 @@ struct RegIsland {
     storeSweepC(k, c_, q);
   }
 
-  __device__ __forceinline__ void warmStartContact(int k, RContact& c_) {
+  // Wall-side folding (WALLA).  Proxy A of a (wall, body) contact is a static body: invMass = invI = 0, v = w = +0, and
+  // nothing ever writes them (setV drops wall rows).  Then, for finite operands and bit for bit:
+  //   vA -= mA * P, wA -= iA * (...)          : +0 - (+-0) = +0                       -> the wall row stays +0, no need to compute it
+  //   dv = vB + Cross(wB, rB) - vA - Cross(wA, rA): X - (+0) = X; X - (+-0) = X unless X is -0 and the subtrahend is -0.  X = vB + t is
+  //       -0 only if vB is -0, and a body velocity is never -0: every write of v / w is a sum or difference with the old value
+  //       (x + y and x - y give -0 only from (-0, -0) / (-0, +0)), a product with a positive factor, or +0 (reset, sleep), and
+  //       every world step adds h * (+0) to v.x (tests/test_oracle_physics.py::test_velocities_never_carry_a_negative_zero).
+  // So the wall terms are dropped from the 180 sweeps (a third of a contact's arithmetic, 4 of its 22 constant words) whenever
+  // every lane that sweeps contact k has a wall on side A - always in scenes without body-body pairs, wave by wave otherwise.
+  template <bool WALLA>
+  __device__ __forceinline__ void warmStartContactT(int k, RContact& c_) {
     const int pA = c_.pA, pB = c_.pB;
-    const SweepC q = loadSweepC(k, c_);
-    BodyMass mAs = M(pA), mBs = M(pB);
+    const SweepC q = loadSweepC<WALLA>(k, c_);
+    BodyMass mAs = WALLA ? BodyMass{0.0f, 0.0f, V2(0.0f, 0.0f)} : M(pA), mBs = WALLA ? getMass(pB - 4) : M(pB);   // B is never a wall
     float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
-    BodyVel va_ = V(pA), vb_ = V(pB);
+    BodyVel va_ = WALLA ? BodyVel{V2(0.0f, 0.0f), 0.0f} : V(pA), vb_ = WALLA ? getVel(pB - 4) : V(pB);
     Vec2 vA = va_.v, vB = vb_.v;
     float wA = va_.w, wB = vb_.w;
     Vec2 normal = q.normal;
@@ -388,25 +399,36 @@ struct RegIsland {
       if (j >= c_.pointCount) break;
       RPoint* vcp = c_.points + j;
       Vec2 P_ = vcp->normalImpulse * normal + vcp->tangentImpulse * tangent;
-      wA -= iA * Cross(q.rA[j], P_);
-      vA -= mA * P_;
+      if constexpr (!WALLA) {
+        wA -= iA * Cross(q.rA[j], P_);
+        vA -= mA * P_;
+      }
       wB += iB * Cross(q.rB[j], P_);
       vB += mB * P_;
     }
     va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
-    setV(pA, va_);
-    setV(pB, vb_);
+    if constexpr (WALLA) {
+      setVel(pB - 4, vb_);
+    } else {
+      setV(pA, va_);
+      setV(pB, vb_);
+    }
+  }
+  __device__ __forceinline__ void warmStartContact(int k, RContact& c_) {
+    if (__ballot(c_.pA >= 4) == 0) warmStartContactT<true>(k, c_);
+    else warmStartContactT<false>(k, c_);
   }
 
   // b2ContactSolver::SolveVelocityConstraints for one contact; returns true iff a non-zero impulse was applied
-  __device__ __forceinline__ bool sweepContact(int k, RContact& c_) {
+  template <bool WALLA>
+  __device__ __forceinline__ bool sweepContactT(int k, RContact& c_) {
     bool changed = false;
     const int pA = c_.pA, pB = c_.pB;
-    const SweepC q = loadSweepC(k, c_);
-    BodyMass mAs = M(pA), mBs = M(pB);
+    const SweepC q = loadSweepC<WALLA>(k, c_);
+    BodyMass mAs = WALLA ? BodyMass{0.0f, 0.0f, V2(0.0f, 0.0f)} : M(pA), mBs = WALLA ? getMass(pB - 4) : M(pB);   // B is never a wall
     float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
     int pointCount = c_.pointCount;
-    BodyVel va_ = V(pA), vb_ = V(pB);
+    BodyVel va_ = WALLA ? BodyVel{V2(0.0f, 0.0f), 0.0f} : V(pA), vb_ = WALLA ? getVel(pB - 4) : V(pB);
     Vec2 vA = va_.v, vB = vb_.v;
     float wA = va_.w, wB = vb_.w;
     Vec2 normal = q.normal;
@@ -416,7 +438,8 @@ struct RegIsland {
     for (int j = 0; j < 2; ++j) {
       if (j >= pointCount) break;
       RPoint* vcp = c_.points + j;
-      Vec2 dv = vB + Cross(wB, q.rB[j]) - vA - Cross(wA, q.rA[j]);
+      Vec2 dv = vB + Cross(wB, q.rB[j]);
+      if constexpr (!WALLA) dv = dv - vA - Cross(wA, q.rA[j]);
       float vt = Dot(dv, tangent) - 0.0f;
       float lambda = q.tangentMass[j] * (-vt);
       float maxFriction = friction * vcp->normalImpulse;
@@ -425,14 +448,17 @@ struct RegIsland {
       vcp->tangentImpulse = newImpulse;
       changed = changed || (lambda != 0.0f);
       Vec2 P_ = lambda * tangent;
-      vA -= mA * P_;
-      wA -= iA * Cross(q.rA[j], P_);
+      if constexpr (!WALLA) {
+        vA -= mA * P_;
+        wA -= iA * Cross(q.rA[j], P_);
+      }
       vB += mB * P_;
       wB += iB * Cross(q.rB[j], P_);
     }
     if (pointCount == 1) {
       RPoint* vcp = c_.points + 0;
-      Vec2 dv = vB + Cross(wB, q.rB[0]) - vA - Cross(wA, q.rA[0]);
+      Vec2 dv = vB + Cross(wB, q.rB[0]);
+      if constexpr (!WALLA) dv = dv - vA - Cross(wA, q.rA[0]);
       float vn = Dot(dv, normal);
       float lambda = -q.normalMass[0] * (vn - q.velocityBias[0]);
       float newImpulse = Max(vcp->normalImpulse + lambda, 0.0f);
@@ -440,16 +466,20 @@ struct RegIsland {
       vcp->normalImpulse = newImpulse;
       changed = changed || (lambda != 0.0f);
       Vec2 P_ = lambda * normal;
-      vA -= mA * P_;
-      wA -= iA * Cross(q.rA[0], P_);
+      if constexpr (!WALLA) {
+        vA -= mA * P_;
+        wA -= iA * Cross(q.rA[0], P_);
+      }
       vB += mB * P_;
       wB += iB * Cross(q.rB[0], P_);
     } else {
       RPoint* cp1 = c_.points + 0;
       RPoint* cp2 = c_.points + 1;
       Vec2 a_ = V2(cp1->normalImpulse, cp2->normalImpulse);
-      Vec2 dv1 = vB + Cross(wB, q.rB[0]) - vA - Cross(wA, q.rA[0]);
-      Vec2 dv2 = vB + Cross(wB, q.rB[1]) - vA - Cross(wA, q.rA[1]);
+      Vec2 dv1 = vB + Cross(wB, q.rB[0]);
+      if constexpr (!WALLA) dv1 = dv1 - vA - Cross(wA, q.rA[0]);
+      Vec2 dv2 = vB + Cross(wB, q.rB[1]);
+      if constexpr (!WALLA) dv2 = dv2 - vA - Cross(wA, q.rA[1]);
       float vn1 = Dot(dv1, normal);
       float vn2 = Dot(dv2, normal);
       Vec2 b;
@@ -484,8 +514,10 @@ struct RegIsland {
         changed = changed || (d.x != 0.0f) || (d.y != 0.0f);
         Vec2 P1 = d.x * normal;
         Vec2 P2 = d.y * normal;
-        vA -= mA * (P1 + P2);
-        wA -= iA * (Cross(q.rA[0], P1) + Cross(q.rA[1], P2));
+        if constexpr (!WALLA) {
+          vA -= mA * (P1 + P2);
+          wA -= iA * (Cross(q.rA[0], P1) + Cross(q.rA[1], P2));
+        }
         vB += mB * (P1 + P2);
         wB += iB * (Cross(q.rB[0], P1) + Cross(q.rB[1], P2));
         cp1->normalImpulse = x.x;
@@ -493,29 +525,46 @@ struct RegIsland {
       }
     }
     va_.v = vA; va_.w = wA; vb_.v = vB; vb_.w = wB;
-    setV(pA, va_);
-    setV(pB, vb_);
+    if constexpr (WALLA) {
+      setVel(pB - 4, vb_);
+    } else {
+      setV(pA, va_);
+      setV(pB, vb_);
+    }
     return changed;
+  }
+  __device__ __forceinline__ bool sweepContact(int k, RContact& c_) {
+    if (__ballot(c_.pA >= 4) == 0) return sweepContactT<true>(k, c_);   // wave-uniform: every sweeping lane has a wall on side A
+    return sweepContactT<false>(k, c_);
   }
 
   // b2PositionSolverManifold + one b2ContactSolver::SolvePositionConstraints pass over one contact; returns min separation
-  template <bool TOI = false>   // TOI: b2ContactSolver::SolveTOIPositionConstraints (b2_toiBaugarte; only the TOI body has mass)
-  __device__ __forceinline__ float positionContact(const RContact& c_, float minSeparation) {
+  // WALLA (see warmStartContactT): the wall row (c = 0, a = 0, no mass) is a constant; K = mA + mB + iA rnA^2 + iB rnB^2 loses its
+  // two zero terms exactly (0 + mB = mB, mB + (+-0) = mB), the wall's own updates are +0 - (+-0) = +0.  The identity rotation is
+  // still multiplied through (1 * x - 0 * y), so every value - signs of zeros included - is the generic path's.
+  template <bool TOI, bool WALLA>   // TOI: b2ContactSolver::SolveTOIPositionConstraints (b2_toiBaugarte; only the TOI body has mass)
+  __device__ __forceinline__ float positionContactT(const RContact& c_, float minSeparation) {
     const int pA = c_.pA, pB = c_.pB;
-    BodyMass mAs = M(pA), mBs = M(pB);
+    BodyMass mAs = WALLA ? BodyMass{0.0f, 0.0f, V2(0.0f, 0.0f)} : M(pA), mBs = WALLA ? getMass(pB - 4) : M(pB);
     float mA = mAs.invMass, iA = mAs.invI, mB = mBs.invMass, iB = mBs.invI;
     Vec2 localCenterA = mAs.lc, localCenterB = mBs.lc;
     float radiusA = c_.radiusA, radiusB = c_.radiusB;
-    BodyPos pa_ = P(pA), pb_ = P(pB);
+    BodyPos pa_ = WALLA ? BodyPos{V2(0.0f, 0.0f), 0.0f} : P(pA), pb_ = WALLA ? getPos(pB - 4) : P(pB);
     Vec2 cA = pa_.c, cB = pb_.c;
     float aA = pa_.a, aB = pb_.a;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (j >= c_.mcount) break;
       Transform xfA, xfB;
-      xfA.q = rotDead(deadQ, c_.pA, aA);
+      if constexpr (WALLA) {
+        xfA.q.s = 0.0f;
+        xfA.q.c = 1.0f;
+        xfA.p = V2(0.0f, 0.0f);
+      } else {
+        xfA.q = rotDead(deadQ, c_.pA, aA);
+        xfA.p = cA - Mul(xfA.q, localCenterA);
+      }
       xfB.q = rotDead(deadQ, c_.pB, aB);
-      xfA.p = cA - Mul(xfA.q, localCenterA);
       xfB.p = cB - Mul(xfB.q, localCenterB);
       Vec2 normal, point;
       float separation;
@@ -547,18 +596,29 @@ struct RegIsland {
       float C = Clamp((TOI ? kToiBaumgarte : kBaumgarte) * (separation + kLinearSlop), -kMaxLinearCorrection, 0.0f);
       float rnA = Cross(rA, normal);
       float rnB = Cross(rB, normal);
-      float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+      float K = WALLA ? mB + iB * rnB * rnB : mA + mB + iA * rnA * rnA + iB * rnB * rnB;
       float impulse = K > 0.0f ? -C / K : 0.0f;
       Vec2 P_ = impulse * normal;
-      cA -= mA * P_;
-      aA -= iA * Cross(rA, P_);
+      if constexpr (!WALLA) {
+        cA -= mA * P_;
+        aA -= iA * Cross(rA, P_);
+      }
       cB += mB * P_;
       aB += iB * Cross(rB, P_);
     }
     pa_.c = cA; pa_.a = aA; pb_.c = cB; pb_.a = aB;
-    setP(pA, pa_);
-    setP(pB, pb_);
+    if constexpr (WALLA) {
+      setPos(pB - 4, pb_);
+    } else {
+      setP(pA, pa_);
+      setP(pB, pb_);
+    }
     return minSeparation;
+  }
+  template <bool TOI = false>
+  __device__ __forceinline__ float positionContact(const RContact& c_, float minSeparation) {
+    if (__ballot(c_.pA >= 4) == 0) return positionContactT<TOI, true>(c_, minSeparation);
+    return positionContactT<TOI, false>(c_, minSeparation);
   }
 
   // ---- b2RevoluteJoint ----

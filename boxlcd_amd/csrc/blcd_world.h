@@ -19,6 +19,7 @@
 #include "blcd_toi.h"
 #include "blcd_toi_wall.h"
 #include "blcd_island_reg.h"
+#include "blcd_collide_wall.h"
 
 #ifndef BLCD_REG_MAXNB
 #define BLCD_REG_MAXNB 7   // largest scene class that uses the staged register island (blcd_island_reg.h); see DESIGN.md §4
@@ -270,6 +271,9 @@ struct Env {
   // one-body configuration keeps two constraint slots in registers; an island that would need more raises FAULT_OVERFLOW
   // (reported through blcd_get_faults) instead of silently dropping physics.
   static constexpr int kMaxC = NB == 1 ? (NP < 2 ? NP : 2) : NP;
+  // One-body classes: side A of every contact is a wall (pairAOf) - its zero-mass, never-moving row is folded out of the hot
+  // loops; the argument that this is bit-neutral is spelled out at RegIsland::warmStartContactT (blcd_island_reg.h).
+  static constexpr bool kWallA = NB == 1;
   static constexpr int kU = kMaxC <= 4 ? kMaxC : 1;   // unroll factor of the constraint loops (full unroll => static vc[] indices)
   static constexpr int kUS = NP <= 4 ? NP : 1;        // unroll factor of the per-slot load/store loops
   const DevScene* S;
@@ -309,6 +313,7 @@ struct Env {
   float wallRad[4];
   Vec2 wallFatLo[4], wallFatHi[4];           // their fat AABBs
   Vec2 wallNrm[4], wallTan[4];               // (edge x 1)/|edge| and edge/|edge|^2: for the conservative TOI early-out only
+  WallK wallK[4];                            // what the wall narrow phase needs of each wall, evaluated once per launch
   static constexpr bool kPairRegs = NP <= 4;   // ByteVec packs up to 4 entries into one register
   ByteVec<4> pairA_, pairB_;                 // pair table (proxy ids), one-body classes
   float crad[kCirc ? NB : 1];                // circles-only scenes: the bodies' shapes
@@ -370,6 +375,7 @@ struct Env {
     pflags.clear();
     toiCount.clear();
     ic.clear();
+#pragma unroll   // must unroll: a rolled loop indexes the member arrays at run time, which sends the whole Env to scratch
     for (int k = 0; k < 4; ++k) {
       wallV0[k] = S->wallShape[k].v[0];
       wallV1[k] = S->wallShape[k].v[1];
@@ -383,6 +389,7 @@ struct Env {
       }
       wallFatLo[k] = S->wallFat[k].lo;
       wallFatHi[k] = S->wallFat[k].hi;
+      wallK[k] = MakeWallK(wallV0[k], wallV1[k], wallRad[k]);
     }
     pairA_.w = pairB_.w = 0;
     if (kPairRegs) {
@@ -585,15 +592,6 @@ struct Env {
     if constexpr (NB == 1) return 4;
     return kPairRegs ? pairB_.get(s) : S->pairs[s].b;
   }
-  __device__ __forceinline__ Shape wallShapeReg(int p) const {  // only type/radius/count/v[0..1] are meaningful
-    Shape w{};
-    w.type = kEdge;
-    w.count = 2;
-    w.radius = selGet(wallRad, p);
-    w.v[0] = selGet(wallV0, p);
-    w.v[1] = selGet(wallV1, p);
-    return w;
-  }
   __device__ __forceinline__ Shape circShapeReg(int i) const {  // kCirc only
     Shape c_{};
     c_.type = kCircle;
@@ -733,15 +731,15 @@ struct Env {
     bool wasTouching = (pflags.get(s) & PF_TOUCHING) != 0;
     Transform xfA = xfOf(pA), xfB = xfOf(pB);
     int ta = typeOf(pA), tb = typeOf(pB);
-    if (ta == kEdge) {
-      const Shape wA = wallShapeReg(pA);
+    if (ta == kEdge) {   // a wall: blcd_collide_wall.h
+      const WallK wA = selGet(wallK, pA);
       if (kCirc) {
-        const Shape cB = circShapeReg(bi(pB));
-        CollideEdgeAndCircle(&m, &wA, xfA, &cB, xfB);
+        CollideWallCircle(&m, wA, cctr[bi(pB)], crad[bi(pB)], xfB);
       } else if (tb == kCircle) {
-        CollideEdgeAndCircle(&m, &wA, xfA, shapeOf(pB), xfB);
+        const Shape* cB = shapeOf(pB);
+        CollideWallCircle(&m, wA, cB->v[0], cB->radius, xfB);
       } else {
-        CollideEdgeAndPolygon(&m, &wA, xfA, shapeOf(pB), xfB);
+        CollideWallPolygon(&m, wA, shapeOf(pB), xfB);
       }
     } else if (ta == kPolygon) {
       if (tb == kCircle) CollidePolygonAndCircle(&m, shapeOf(pA), xfA, shapeOf(pB), xfB);
@@ -953,12 +951,14 @@ struct Env {
         if (j >= c_.pointCount) break;
         VCPoint* vcp = c_.points + j;
         Vec2 P = vcp->normalImpulse * normal + vcp->tangentImpulse * tangent;
-        wA -= iA * Cross(vcp->rA, P);
-        vA -= mA * P;
+        if constexpr (!kWallA) {
+          wA -= iA * Cross(vcp->rA, P);
+          vA -= mA * P;
+        }
         wB += iB * Cross(vcp->rB, P);
         vB += mB * P;
       }
-      setVel(pA, vA, wA);
+      if constexpr (!kWallA) setVel(pA, vA, wA);
       setVel(pB, vB, wB);
     }
   }
@@ -986,7 +986,8 @@ struct Env {
       for (int j = 0; j < kMP; ++j) {
         if (j >= pointCount) break;
         VCPoint* vcp = c_.points + j;
-        Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+        Vec2 dv = vB + Cross(wB, vcp->rB);
+        if constexpr (!kWallA) dv = dv - vA - Cross(wA, vcp->rA);
         float vt = Dot(dv, tangent) - 0.0f;
         float lambda = vcp->tangentMass * (-vt);
         float maxFriction = friction * vcp->normalImpulse;
@@ -995,14 +996,17 @@ struct Env {
         vcp->tangentImpulse = newImpulse;
         changed = changed || (lambda != 0.0f);
         Vec2 P = lambda * tangent;
-        vA -= mA * P;
-        wA -= iA * Cross(vcp->rA, P);
+        if constexpr (!kWallA) {
+          vA -= mA * P;
+          wA -= iA * Cross(vcp->rA, P);
+        }
         vB += mB * P;
         wB += iB * Cross(vcp->rB, P);
       }
       if (kMP == 1 || pointCount == 1) {
         VCPoint* vcp = c_.points + 0;
-        Vec2 dv = vB + Cross(wB, vcp->rB) - vA - Cross(wA, vcp->rA);
+        Vec2 dv = vB + Cross(wB, vcp->rB);
+        if constexpr (!kWallA) dv = dv - vA - Cross(wA, vcp->rA);
         float vn = Dot(dv, normal);
         float lambda = -vcp->normalMass * (vn - vcp->velocityBias);
         float newImpulse = Max(vcp->normalImpulse + lambda, 0.0f);
@@ -1010,16 +1014,22 @@ struct Env {
         vcp->normalImpulse = newImpulse;
         changed = changed || (lambda != 0.0f);
         Vec2 P = lambda * normal;
-        vA -= mA * P;
-        wA -= iA * Cross(vcp->rA, P);
+        if constexpr (!kWallA) {
+          vA -= mA * P;
+          wA -= iA * Cross(vcp->rA, P);
+        }
         vB += mB * P;
         wB += iB * Cross(vcp->rB, P);
       } else {
         VCPoint* cp1 = c_.points + 0;
         VCPoint* cp2 = c_.points + 1;
         Vec2 a_ = V2(cp1->normalImpulse, cp2->normalImpulse);
-        Vec2 dv1 = vB + Cross(wB, cp1->rB) - vA - Cross(wA, cp1->rA);
-        Vec2 dv2 = vB + Cross(wB, cp2->rB) - vA - Cross(wA, cp2->rA);
+        Vec2 dv1 = vB + Cross(wB, cp1->rB);
+        Vec2 dv2 = vB + Cross(wB, cp2->rB);
+        if constexpr (!kWallA) {
+          dv1 = dv1 - vA - Cross(wA, cp1->rA);
+          dv2 = dv2 - vA - Cross(wA, cp2->rA);
+        }
         float vn1 = Dot(dv1, normal);
         float vn2 = Dot(dv2, normal);
         Vec2 b;
@@ -1055,15 +1065,17 @@ struct Env {
           changed = changed || (d.x != 0.0f) || (d.y != 0.0f);
           Vec2 P1 = d.x * normal;
           Vec2 P2 = d.y * normal;
-          vA -= mA * (P1 + P2);
-          wA -= iA * (Cross(cp1->rA, P1) + Cross(cp2->rA, P2));
+          if constexpr (!kWallA) {
+            vA -= mA * (P1 + P2);
+            wA -= iA * (Cross(cp1->rA, P1) + Cross(cp2->rA, P2));
+          }
           vB += mB * (P1 + P2);
           wB += iB * (Cross(cp1->rB, P1) + Cross(cp2->rB, P2));
           cp1->normalImpulse = x.x;
           cp2->normalImpulse = x.y;
         }
       }
-      setVel(pA, vA, wA);
+      if constexpr (!kWallA) setVel(pA, vA, wA);
       setVel(pB, vB, wB);
     }
     return changed;
@@ -1150,15 +1162,17 @@ struct Env {
         float C = Clamp((toiMode ? kToiBaumgarte : kBaumgarte) * (separation + kLinearSlop), -kMaxLinearCorrection, 0.0f);
         float rnA = Cross(rA, normal);
         float rnB = Cross(rB, normal);
-        float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        float K = kWallA ? mB + iB * rnB * rnB : mA + mB + iA * rnA * rnA + iB * rnB * rnB;
         float impulse = K > 0.0f ? -C / K : 0.0f;
         Vec2 P = impulse * normal;
-        cA -= mA * P;
-        aA -= iA * Cross(rA, P);
+        if constexpr (!kWallA) {
+          cA -= mA * P;
+          aA -= iA * Cross(rA, P);
+        }
         cB += mB * P;
         aB += iB * Cross(rB, P);
       }
-      setPos(pA, cA, aA);
+      if constexpr (!kWallA) setPos(pA, cA, aA);
       setPos(pB, cB, aB);
     }
     return minSeparation;

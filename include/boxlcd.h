@@ -245,7 +245,7 @@ int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches);
  * out8 = { first passes: lanes entered live, lanes that left suspended, waves, passes per chunk;
  *          later passes: lanes entered live, lanes that left suspended, waves, lane threshold }. */
 int blcd_sched_stats(blcd_handle h, uint64_t* out8);
-int blcd_debug_wave_times(blcd_handle h, uint64_t* out, int32_t cap);      /* per-wave ticks (100 MHz) of the last step launch; needs BLCD_WAVETIMES=1 */
+int blcd_debug_wave_times(blcd_handle h, uint64_t* out, int32_t cap);      /* per-wave ticks (100 MHz) of the last step launch; needs a -DBLCD_WAVETIMES build and BLCD_WAVETIMES=1 */
 int blcd_debug_world_step(blcd_handle h, int32_t n_world_steps);           /* n x b2World::Step only */
 int blcd_debug_set_motor_speeds(blcd_handle h, const float* actions);       /* the action half of step() only */
 int blcd_debug_dump(blcd_handle h, float* bodies, float* joints, float* pairs); /* host [n_envs][..][FLOATS] */
