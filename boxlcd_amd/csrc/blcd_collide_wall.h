@@ -10,7 +10,7 @@
 //     zero could (MulT(xfA, xfB) below),
 //   * contact ids are built as the 32-bit keys they are stored as, clip vertices are scalars.
 // The arithmetic that produces a manifold is upstream's, operation for operation; the CPU oracle keeps upstream's generic
-// routines (oracle/b2o_collide.h) and the parity suite compares manifolds bit for bit after every world step.
+// routines and the parity suite compares manifolds bit for bit after every world step.
 #pragma once
 #include "blcd_collide.h"
 
