@@ -464,6 +464,17 @@ static int lower_scene(const blcd_scene_desc& d, DevScene* S) {
     ShapeComputeAABB(&S->wallShape[i], &aabb, ident);
     S->wallFat[i].lo = aabb.lo - V2(kAabbExtension, kAabbExtension);
     S->wallFat[i].hi = aabb.hi + V2(kAabbExtension, kAabbExtension);
+    // per-wall constants of the wall narrow phase and of the TOI early-out: evaluated here once (IEEE sqrt / divide, no contraction:
+    // the host's float arithmetic is the device's), read by the kernels through the scalar path - as VALU results computed at
+    // kernel entry they occupied ~70 vector registers per lane for wave-uniform values
+    S->wallK[i] = MakeWallK(S->wallShape[i].v[0], S->wallShape[i].v[1], S->wallShape[i].radius);
+    {
+      const Vec2 ed = S->wallShape[i].v[1] - S->wallShape[i].v[0];
+      const float len2 = Dot(ed, ed);
+      const float inv = 1.0f / sqrtf(len2);
+      S->wallNrm[i] = V2(ed.y * inv, -ed.x * inv);   // Cross(ed, r) * inv == Dot(r, wallNrm)
+      S->wallTan[i] = V2(ed.x / len2, ed.y / len2);
+    }
   }
   for (int i = 0; i < d.n_shapes; ++i) S->shapes[i] = build_shape(d.shapes[i]);
   for (int i = 0; i < d.n_bodies; ++i) {

@@ -18,8 +18,8 @@
 #include <utility>
 #include "blcd_toi.h"
 #include "blcd_toi_wall.h"
-#include "blcd_island_reg.h"
 #include "blcd_collide_wall.h"
+#include "blcd_island_reg.h"
 
 #ifndef BLCD_REG_MAXNB
 #define BLCD_REG_MAXNB 7   // largest scene class that uses the staged register island (blcd_island_reg.h); see DESIGN.md §4
@@ -85,6 +85,8 @@ struct DevScene {
   int dbgSkip;  // only read by -DBLCD_ABLATION builds (BLCD_DEBUG_SKIP: 1 collide, 2 solve, 4 TOI, 8 everything; results are wrong when set)
   Shape wallShape[4];
   AABB wallFat[4];
+  WallK wallK[4];                 // blcd_collide_wall.h: what the wall narrow phase needs of each wall (filled on the host)
+  Vec2 wallNrm[4], wallTan[4];    // (edge x 1)/|edge| and edge/|edge|^2: the conservative TOI early-out
   Shape shapes[24];
   DevBody bodies[20];
   int bodyKind[20];   // 0 object, 1 robot root, 2 robot link: colours of the RGB render only
@@ -292,7 +294,75 @@ struct Env {
   ByteVec<NP> pflags;
   ByteVec<NP> toiCount;
   float toi[NP];
-  Manifold man[NP];
+  // Contact manifolds (15 state words per pair slot), indexed with run-time slot ids.  Three homes:
+  //  * one-body classes: the wave's LDS block [word][lane] (word = 15 * slot + field, 15 KB per wave): a slot id is an address - no
+  //    48 / 64 v_cndmask select chain per read / write - and 64 fewer long-lived vector registers: the general one-body kernel
+  //    drops from 512 to 414 registers and its velocity sweep from 286 to 238 instructions (80 -> 16 v_accvgpr_read: the loop's
+  //    constants were being parked in AGPRs), the circles-only one from 363 to 212, i.e. no AGPR traffic at all
+  //    (Dropbox-100k +10 %);
+  //  * BLCD_MAN_LDS=2 adds the two-body classes (34.5 KB per wave; measured: Object2-200k -4 % - fifteen ds_read against four
+  //    scratch_load_dwordx4 per manifold - so off by default);
+  //  * otherwise: NP <= 4 registers behind select chains (selGet / selSet), larger classes plain indexing (scratch).
+#ifndef BLCD_MAN_LDS
+#define BLCD_MAN_LDS 1
+#endif
+  static constexpr bool kManLds = BLCD_MAN_LDS >= 1 && NB <= BLCD_MAN_LDS;
+  static constexpr int kManWords = 15;
+  Manifold man[kManLds ? 1 : NP];
+  float* ML;   // kManLds: this lane's column of the manifold block
+  static __device__ __forceinline__ float* manLdsBase() {
+    __shared__ float blk[kManWords * NP * 64];
+    return blk;
+  }
+  __device__ __forceinline__ Manifold manGet(int s) const {
+    if constexpr (kManLds) {
+      const float* p = ML + 64 * kManWords * s;
+      Manifold m;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        m.points[k].localPoint = V2(p[64 * (5 * k)], p[64 * (5 * k + 1)]);
+        m.points[k].normalImpulse = p[64 * (5 * k + 2)];
+        m.points[k].tangentImpulse = p[64 * (5 * k + 3)];
+        m.points[k].id.key = __float_as_uint(p[64 * (5 * k + 4)]);
+      }
+      m.localNormal = V2(p[64 * 10], p[64 * 11]);
+      m.localPoint = V2(p[64 * 12], p[64 * 13]);
+      const int tc = __float_as_int(p[64 * 14]);
+      m.type = tc & 0xff;
+      m.pointCount = tc >> 8;
+      return m;
+    } else {
+      return selGet(man, s);
+    }
+  }
+  __device__ __forceinline__ void manSet(int s, const Manifold& m) {
+    if constexpr (kManLds) {
+      float* p = ML + 64 * kManWords * s;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        p[64 * (5 * k)] = m.points[k].localPoint.x;
+        p[64 * (5 * k + 1)] = m.points[k].localPoint.y;
+        p[64 * (5 * k + 2)] = m.points[k].normalImpulse;
+        p[64 * (5 * k + 3)] = m.points[k].tangentImpulse;
+        p[64 * (5 * k + 4)] = __uint_as_float(m.points[k].id.key);
+      }
+      p[64 * 10] = m.localNormal.x;
+      p[64 * 11] = m.localNormal.y;
+      p[64 * 12] = m.localPoint.x;
+      p[64 * 13] = m.localPoint.y;
+      p[64 * 14] = __int_as_float((m.type & 0xff) | (m.pointCount << 8));
+    } else {
+      selSet(man, s, m);
+    }
+  }
+  __device__ __forceinline__ void manClearCount(int s) {   // a new contact starts with no points; everything else stays as it was
+    if constexpr (kManLds) {
+      float* p = ML + 64 * kManWords * s;
+      p[64 * 14] = __int_as_float(__float_as_int(p[64 * 14]) & 0xff);
+    } else {
+      man[s].pointCount = 0;
+    }
+  }
   // --- joints ---
   Vec3 jimp[NJ > 0 ? NJ : 1];
   float jmotor[NJ > 0 ? NJ : 1], jspeed[NJ > 0 ? NJ : 1], jref[NJ > 0 ? NJ : 1];
@@ -351,6 +421,8 @@ struct Env {
   // ------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void load(const DevScene* scene, const float* __restrict__ st, int N, int e) {
     S = scene;
+    if constexpr (kManLds) ML = manLdsBase() + threadIdx.x;
+    else ML = nullptr;
     if constexpr (SCHED) {
       gst = const_cast<float*>(st) + e;
       gN = N;
@@ -380,16 +452,11 @@ struct Env {
       wallV0[k] = S->wallShape[k].v[0];
       wallV1[k] = S->wallShape[k].v[1];
       wallRad[k] = S->wallShape[k].radius;
-      {
-        const Vec2 ed = wallV1[k] - wallV0[k];
-        const float len2 = Dot(ed, ed);
-        const float inv = 1.0f / sqrtf(len2);
-        wallNrm[k] = V2(ed.y * inv, -ed.x * inv);   // Cross(ed, r) * inv == Dot(r, wallNrm)
-        wallTan[k] = V2(ed.x / len2, ed.y / len2);
-      }
+      wallNrm[k] = S->wallNrm[k];
+      wallTan[k] = S->wallTan[k];
       wallFatLo[k] = S->wallFat[k].lo;
       wallFatHi[k] = S->wallFat[k].hi;
-      wallK[k] = MakeWallK(wallV0[k], wallV1[k], wallRad[k]);
+      wallK[k] = S->wallK[k];
     }
     pairA_.w = pairB_.w = 0;
     if (kPairRegs) {
@@ -437,7 +504,7 @@ struct Env {
       int fl = __float_as_int(p[0]);
       pflags.set(s, fl);
       int tc = __float_as_int(p[(size_t)1 * N]);
-      Manifold& m = man[s];
+      Manifold m;
       m.type = tc & 0xff;
       m.pointCount = tc >> 8;
       m.localNormal = V2(p[(size_t)2 * N], p[(size_t)3 * N]);
@@ -449,6 +516,8 @@ struct Env {
         m.points[k].tangentImpulse = r[(size_t)3 * N];
         m.points[k].id.key = __float_as_uint(r[(size_t)4 * N]);
       }
+      if constexpr (kManLds) manSet(s, m);
+      else man[s] = m;
       toiCount.set(s, 0);
       selSet(toi, s, (float)(1.0f));
     }
@@ -510,7 +579,9 @@ struct Env {
       if (s >= np) break;
       float* p = pp + (size_t)(s * kPairFields) * N;
       p[0] = __int_as_float((int)(pflags.get(s) & (PF_EXISTS | PF_TOUCHING | PF_ENABLED)));
-      const Manifold& m = man[s];
+      Manifold m;
+      if constexpr (kManLds) m = manGet(s);
+      else m = man[s];
       p[(size_t)1 * N] = __int_as_float((m.type & 0xff) | (m.pointCount << 8));
       p[(size_t)2 * N] = m.localNormal.x;
       p[(size_t)3 * N] = m.localNormal.y;
@@ -711,7 +782,7 @@ struct Env {
       wl.insertFront(nc, s);
       ++nc;
       pflags.set(s, PF_EXISTS | PF_ENABLED);
-      man[s].pointCount = 0;
+      manClearCount(s);
       toiCount.set(s, 0);
       selSet(toi, s, (float)(1.0f));
       wake(pa_);
@@ -725,7 +796,7 @@ struct Env {
   __device__ __forceinline__ void updateContact(int s) {
     int pA, pB;
     slotAB(s, &pA, &pB);
-    Manifold m = selGet(man, s);
+    Manifold m = manGet(s);
     Manifold oldManifold = m;
     pflags.orBits(s, PF_ENABLED);
     bool wasTouching = (pflags.get(s) & PF_TOUCHING) != 0;
@@ -774,7 +845,7 @@ struct Env {
       wake(pB);
     }
     if (touching) pflags.orBits(s, PF_TOUCHING); else pflags.clearBits(s, PF_TOUCHING);
-    selSet(man, s, m);
+    manSet(s, m);
   }
 
   __device__ __forceinline__ void collide() {
@@ -787,14 +858,14 @@ struct Env {
       if (activeA || activeB) {
         if (!TestOverlap(fatOf(pa_), fatOf(pb_))) {
           // b2ContactManager::Destroy + b2Contact::Destroy
-          Manifold dm = selGet(man, s);
+          Manifold dm = manGet(s);
           if (dm.pointCount > 0) {
             wake(pa_);
             wake(pb_);
           }
           pflags.set(s, 0);
           dm.pointCount = 0;
-          selSet(man, s, dm);
+          manSet(s, dm);
           continue;
         }
         updateContact(s);
@@ -836,7 +907,7 @@ struct Env {
       if (i >= count) break;
       int s = ic.get(i);
       VC& c_ = vc[i];
-      const Manifold m = selGet(man, s);
+      const Manifold m = manGet(s);
       c_.slot = s;
       slotAB(s, &c_.pA, &c_.pB);
       c_.friction = S->pairs[s].friction;
@@ -869,7 +940,7 @@ struct Env {
     for (int i = 0; i < kMaxC; ++i) {
       if (i >= count) break;
       VC& c_ = vc[i];
-      const Manifold mcopy = selGet(man, c_.slot);
+      const Manifold mcopy = manGet(c_.slot);
       const Manifold* manifold = &mcopy;
       int pA = c_.pA, pB = c_.pB;
       float radiusA = radiusOf(pA), radiusB = radiusOf(pB);
@@ -1086,7 +1157,7 @@ struct Env {
     for (int i = 0; i < kMaxC; ++i) {
       if (i >= count) break;
       VC& c_ = vc[i];
-      Manifold m = selGet(man, c_.slot);
+      Manifold m = manGet(c_.slot);
 #pragma unroll
       for (int j = 0; j < kMP; ++j) {
         if (j < c_.pointCount) {
@@ -1094,7 +1165,7 @@ struct Env {
           m.points[j].tangentImpulse = c_.points[j].tangentImpulse;
         }
       }
-      selSet(man, c_.slot, m);
+      manSet(c_.slot, m);
     }
   }
 
@@ -1105,7 +1176,7 @@ struct Env {
     for (int i = 0; i < kMaxC; ++i) {
       if (i >= count) break;
       VC& c_ = vc[i];
-      const Manifold m = selGet(man, c_.slot);
+      const Manifold m = manGet(c_.slot);
       int pA = c_.pA, pB = c_.pB;
       Vec2 localCenterA = lcOf(pA), localCenterB = lcOf(pB);
       float mA = mOf(pA), iA = iOf(pA), mB = mOf(pB), iB = iOf(pB);
@@ -1452,8 +1523,37 @@ struct Env {
     }
   }
   // returns true when the lane suspends at sweep kYieldSweeps (only asked of joint-free islands, see kCanYield)
+  // Start a fresh live range in a VGPR right here (empty asm, value unchanged).  The sweep loop's constants are defined long before
+  // the loop (constraint initialisation) and the register allocator - 512 registers, half of them AGPRs that no VALU instruction
+  // can read - parks them in AGPRs in favour of state the loop never touches: 80 of the 286 instructions of a one-body sweep were
+  // v_accvgpr_read.  A value that is born at the loop's door and dies behind it gets a register of its own.
+#ifndef BLCD_NO_PIN
+#define BLCD_PIN(x_) asm volatile("" : "+v"(x_))
+#else
+#define BLCD_PIN(x_) do {} while (0)
+#endif
+  __device__ __forceinline__ void pinSweepConstants() {
+    if constexpr (NB == 1) {
+#pragma unroll
+      for (int k = 0; k < kMaxC; ++k) {
+        VC& c_ = vc[k];
+        BLCD_PIN(c_.normal.x); BLCD_PIN(c_.normal.y); BLCD_PIN(c_.friction);
+        if constexpr (kMP == 2) {
+          BLCD_PIN(c_.K.ex.x); BLCD_PIN(c_.K.ex.y); BLCD_PIN(c_.K.ey.x); BLCD_PIN(c_.K.ey.y);
+          BLCD_PIN(c_.normalMass.ex.x); BLCD_PIN(c_.normalMass.ex.y); BLCD_PIN(c_.normalMass.ey.x); BLCD_PIN(c_.normalMass.ey.y);
+        }
+#pragma unroll
+        for (int j = 0; j < kMP; ++j) {
+          VCPoint& p_ = c_.points[j];
+          BLCD_PIN(p_.rB.x); BLCD_PIN(p_.rB.y); BLCD_PIN(p_.normalMass); BLCD_PIN(p_.tangentMass); BLCD_PIN(p_.velocityBias);
+        }
+      }
+      BLCD_PIN(invMass[0]); BLCD_PIN(invI[0]);
+    }
+  }
   __device__ __forceinline__ bool velocitySweeps(uint32_t ibmask, int nic, int nij, float h, int startIt = 0, bool mayYield = false) {
     const int velIters = S->velIters;
+    pinSweepConstants();
     bool watch = nij == 0 && nic > 0 && nic <= kCycNC && (ibmask >> kCycNB) == 0;
     CycRow cyc[kCycP];
     for (int it = startIt; it < velIters; ++it) {
@@ -1602,7 +1702,7 @@ struct Env {
       if (k < nic) {
         int s = ic.get(k);
         RContact& c_ = R.ct[k];
-        const Manifold m = selGet(man, s);
+        const Manifold m = manGet(s);
         mans[k] = m;
         slotAB(s, &c_.pA, &c_.pB);
         c_.friction = S->pairs[s].friction;
@@ -1728,7 +1828,7 @@ struct Env {
                 m.points[j].normalImpulse = R.ct[k].points[j].normalImpulse;
                 m.points[j].tangentImpulse = R.ct[k].points[j].tangentImpulse;
               }
-            selSet(man, s, m);
+            manSet(s, m);
           }
         }
         velMask |= 1u << seed;
@@ -1747,7 +1847,7 @@ struct Env {
             m.points[j].normalImpulse = R.ct[k].points[j].normalImpulse;
             m.points[j].tangentImpulse = R.ct[k].points[j].tangentImpulse;
           }
-        selSet(man, s, m);
+        manSet(s, m);
       }
     }
     // integrate positions
@@ -1865,7 +1965,7 @@ struct Env {
       if (k < nic) {
         int s = ic.get(k);
         RContact& c_ = R.ct[k];
-        const Manifold m = selGet(man, s);
+        const Manifold m = manGet(s);
         mans[k] = m;
         slotAB(s, &c_.pA, &c_.pB);
         c_.friction = S->pairs[s].friction;
@@ -1986,7 +2086,7 @@ struct Env {
 #pragma unroll kU
       for (int k = 0; k < kMaxC; ++k) {
         if (k >= nic) break;
-        const Manifold m = selGet(man, vc[k].slot);
+        const Manifold m = manGet(vc[k].slot);
 #pragma unroll
         for (int j = 0; j < kMP; ++j) {
           vc[k].points[j].normalImpulse = m.points[j].normalImpulse;     // stored raw at suspension (no dtRatio)
