@@ -1041,6 +1041,12 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     h->rebinEvery = (h->hostScene.nj == 0 && simds > 0 && (long long)n_envs > 64LL * simds) ? 1 : 0;
   }
   if (const char* ev = getenv("BLCD_REBIN")) h->rebinEvery = atoi(ev);
+  // Chunk length of the re-binned one-body batches.  Every chunk boundary costs a sort of the slots and the wait for the chunk's
+  // slowest wave; since the one-body kernels lost a quarter of their instructions (round 3: wall-side folding, LDS manifolds)
+  // those fixed costs weigh more than the better grouping of a 20-step interval buys (200-step rollouts, tools/chunk_sweep.sh):
+  // Bounce-100k 1.84e9 (20) -> 2.02e9 (50) -> 2.12e9 (100); Dropbox-100k 6.4e8 (20) -> 6.6e8 (40, 50) -> 6.4e8 (100).
+  // Multi-body batches keep 20 (Object2-200k: 6.3e7 / 6.1e7 / 5.8e7 at 10 / 20 / 40).  Results do not depend on the chunking.
+  if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 1) h->rolloutChunk = kCfgs[h->cfg].sh == 1 ? 100 : 50;
   if (h->hostScene.nb <= 7) {
     if (const char* ev = getenv("BLCD_ASYNC")) h->asyncBudget = atoi(ev) > 0 ? atoi(ev) : 0;
     if (h->asyncBudget > 0) {

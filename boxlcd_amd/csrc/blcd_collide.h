@@ -43,23 +43,19 @@ BLCD_HD static inline void ShapeSetAsBox(Shape* s, float hx, float hy) {
 
 // ComputeCentroid (b2PolygonShape.cpp)
 BLCD_HD static inline Vec2 ComputeCentroid(const Vec2* vs, int count) {
-  Vec2 c = V2(0.0f, 0.0f);
+  // area-weighted mean of the centroids of the fan of triangles (origin, vs[i], vs[i+1]); the origin's zero terms stay in the sums
+  const Vec2 origin = V2(0.0f, 0.0f);
+  const float third = 1.0f / 3.0f;
+  Vec2 sum = V2(0.0f, 0.0f);
   float area = 0.0f;
-  Vec2 pRef = V2(0.0f, 0.0f);
-  const float inv3 = 1.0f / 3.0f;
   for (int i = 0; i < count; ++i) {
-    Vec2 p1 = pRef;
-    Vec2 p2 = vs[i];
-    Vec2 p3 = i + 1 < count ? vs[i + 1] : vs[0];
-    Vec2 e1 = p2 - p1;
-    Vec2 e2 = p3 - p1;
-    float D = Cross(e1, e2);
-    float triangleArea = 0.5f * D;
-    area += triangleArea;
-    c += triangleArea * inv3 * (p1 + p2 + p3);
+    const Vec2 a = vs[i], b = vs[i + 1 < count ? i + 1 : 0];
+    const float tri = 0.5f * Cross(a - origin, b - origin);
+    area += tri;
+    sum += tri * third * (origin + a + b);
   }
-  c *= 1.0f / area;
-  return c;
+  sum *= 1.0f / area;
+  return sum;
 }
 
 // b2PolygonShape::Set (b2PolygonShape.cpp, 2.3.1: weld, gift-wrap hull from the right-most point, normals, centroid)
@@ -199,34 +195,24 @@ BLCD_HD static inline void CircleComputeAABB(const Shape* s, AABB* aabb, const T
   aabb->lo = V2(p.x - s->radius, p.y - s->radius);
   aabb->hi = V2(p.x + s->radius, p.y + s->radius);
 }
+// An edge is treated as the two-vertex polygon it is: Min / Max over (v1, v2) is the loop's first step.
 BLCD_HD static inline void ShapeComputeAABB(const Shape* s, AABB* aabb, const Transform& xf) {
   if (s->type == kCircle) {
     CircleComputeAABB(s, aabb, xf);
     return;
   }
-  if (s->type == kEdge) {
-    Vec2 v1 = Mul(xf, s->v[0]);
-    Vec2 v2 = Mul(xf, s->v[1]);
-    Vec2 lower = Min(v1, v2);
-    Vec2 upper = Max(v1, v2);
-    Vec2 r = V2(s->radius, s->radius);
-    aabb->lo = lower - r;
-    aabb->hi = upper + r;
-    return;
-  }
-  Vec2 lower = Mul(xf, s->v[0]);
-  Vec2 upper = lower;
+  const int nv = s->type == kEdge ? 2 : s->count;
+  Vec2 lo = Mul(xf, s->v[0]), hi = lo;
 #pragma unroll
   for (int i = 1; i < kShapeVerts; ++i) {
-    if (i < s->count) {
-      Vec2 v = Mul(xf, s->v[i]);
-      lower = Min(lower, v);
-      upper = Max(upper, v);
+    if (i < nv) {
+      const Vec2 w = Mul(xf, s->v[i]);
+      lo = Min(lo, w);
+      hi = Max(hi, w);
     }
   }
-  Vec2 r = V2(s->radius, s->radius);
-  aabb->lo = lower - r;
-  aabb->hi = upper + r;
+  aabb->lo = lo - V2(s->radius, s->radius);
+  aabb->hi = hi + V2(s->radius, s->radius);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -252,60 +238,58 @@ struct Manifold {
   int type;
   int pointCount;
 };
-struct ClipVertex {
-  Vec2 v;
-  ContactID id;
-};
 
+// b2ContactFeature as stored: indexA | indexB << 8 | typeA << 16 | typeB << 24
+BLCD_HD static inline uint32_t FeatureKey(int indexA, int indexB, int typeA, int typeB) {
+  return (uint32_t)(indexA & 0xff) | ((uint32_t)(indexB & 0xff) << 8) | ((uint32_t)typeA << 16) | ((uint32_t)typeB << 24);
+}
+BLCD_HD static inline uint32_t SwapFeatureSides(uint32_t k) {   // (indexA, typeA) <-> (indexB, typeB)
+  return ((k & 0x00ff00ffu) << 8) | ((k >> 8) & 0x00ff00ffu);
+}
+
+// cond ? a : b on the four words of a transform.  (A conditional expression on the objects themselves is a select of
+// ADDRESSES, which keeps both operands - and whatever struct they are members of - in memory.)
+BLCD_HD static inline Transform PickXf(bool first, const Transform& a, const Transform& b) {
+  Transform t;
+  t.p.x = first ? a.p.x : b.p.x;
+  t.p.y = first ? a.p.y : b.p.y;
+  t.q.s = first ? a.q.s : b.q.s;
+  t.q.c = first ? a.q.c : b.q.c;
+  return t;
+}
+
+// World-space contact normal and mid-surface points of a manifold (b2WorldManifold::Initialize, b2Collision.cpp; the solver
+// never reads the separations it also computes).  The two face cases are one computation with the roles of the bodies
+// exchanged: R carries the reference face, I the incident points; 0.5 (cA + cB) does not care which of the two is which.
 struct WorldManifold {
   Vec2 normal;
   Vec2 points[kMaxManifoldPoints];
-  float separations[kMaxManifoldPoints];
-  // b2WorldManifold::Initialize (b2Collision.cpp)
   BLCD_HD void Initialize(const Manifold* manifold, const Transform& xfA, float radiusA, const Transform& xfB, float radiusB) {
     if (manifold->pointCount == 0) return;
-    switch (manifold->type) {
-      case kManifoldCircles: {
-        normal = V2(1.0f, 0.0f);
-        Vec2 pointA = Mul(xfA, manifold->localPoint);
-        Vec2 pointB = Mul(xfB, manifold->points[0].localPoint);
-        if (DistanceSquared(pointA, pointB) > kEpsilon * kEpsilon) {
-          normal = pointB - pointA;
-          Normalize(normal);
-        }
-        Vec2 cA = pointA + radiusA * normal;
-        Vec2 cB = pointB - radiusB * normal;
-        points[0] = 0.5f * (cA + cB);
-        separations[0] = Dot(cB - cA, normal);
-      } break;
-      case kManifoldFaceA: {
-        normal = Mul(xfA.q, manifold->localNormal);
-        Vec2 planePoint = Mul(xfA, manifold->localPoint);
-#pragma unroll
-        for (int i = 0; i < kMaxManifoldPoints; ++i) {
-          if (i >= manifold->pointCount) break;
-          Vec2 clipPoint = Mul(xfB, manifold->points[i].localPoint);
-          Vec2 cA = clipPoint + (radiusA - Dot(clipPoint - planePoint, normal)) * normal;
-          Vec2 cB = clipPoint - radiusB * normal;
-          points[i] = 0.5f * (cA + cB);
-          separations[i] = Dot(cB - cA, normal);
-        }
-      } break;
-      case kManifoldFaceB: {
-        normal = Mul(xfB.q, manifold->localNormal);
-        Vec2 planePoint = Mul(xfB, manifold->localPoint);
-#pragma unroll
-        for (int i = 0; i < kMaxManifoldPoints; ++i) {
-          if (i >= manifold->pointCount) break;
-          Vec2 clipPoint = Mul(xfA, manifold->points[i].localPoint);
-          Vec2 cB = clipPoint + (radiusB - Dot(clipPoint - planePoint, normal)) * normal;
-          Vec2 cA = clipPoint - radiusA * normal;
-          points[i] = 0.5f * (cA + cB);
-          separations[i] = Dot(cA - cB, normal);
-        }
-        normal = -normal;
-      } break;
+    if (manifold->type == kManifoldCircles) {
+      const Vec2 onA = Mul(xfA, manifold->localPoint), onB = Mul(xfB, manifold->points[0].localPoint);
+      normal = V2(1.0f, 0.0f);
+      if (DistanceSquared(onA, onB) > kEpsilon * kEpsilon) {
+        normal = onB - onA;
+        Normalize(normal);
+      }
+      points[0] = 0.5f * ((onA + radiusA * normal) + (onB - radiusB * normal));
+      return;
     }
+    const bool refIsA = manifold->type == kManifoldFaceA;
+    const Transform xfR = PickXf(refIsA, xfA, xfB), xfI = PickXf(refIsA, xfB, xfA);
+    const float radiusR = refIsA ? radiusA : radiusB, radiusI = refIsA ? radiusB : radiusA;
+    const Vec2 n = Mul(xfR.q, manifold->localNormal);
+    const Vec2 plane = Mul(xfR, manifold->localPoint);
+#pragma unroll
+    for (int i = 0; i < kMaxManifoldPoints; ++i) {
+      if (i >= manifold->pointCount) break;
+      const Vec2 clip = Mul(xfI, manifold->points[i].localPoint);
+      const Vec2 onRef = clip + (radiusR - Dot(clip - plane, n)) * n;
+      const Vec2 onInc = clip - radiusI * n;
+      points[i] = 0.5f * (onRef + onInc);
+    }
+    normal = refIsA ? n : -n;
   }
 };
 
@@ -320,114 +304,91 @@ BLCD_HD static inline void PutManifoldPoint(Manifold* m, int idx, const Manifold
   }
 }
 
-// b2ClipSegmentToLine (b2Collision.cpp)
-BLCD_HD static inline int ClipSegmentToLine(ClipVertex vOut[2], const ClipVertex vIn[2], Vec2 normal, float offset, int vertexIndexA) {
-  // Same selection as Box2D's `vOut[numOut++] = ...` sequence, written without run-time indexed stores (register
-  // residency): when the segment crosses the line exactly one end point is inside, so the interpolated vertex lands in
-  // vOut[1]; when both are inside vOut = vIn.
-  float distance0 = Dot(normal, vIn[0].v) - offset;
-  float distance1 = Dot(normal, vIn[1].v) - offset;
-  const bool in0 = distance0 <= 0.0f, in1 = distance1 <= 0.0f;
-  int numOut = (in0 ? 1 : 0) + (in1 ? 1 : 0);
-  ClipVertex o0 = in0 ? vIn[0] : vIn[1];
-  ClipVertex o1 = vIn[1];
-  if (distance0 * distance1 < 0.0f) {
-    float interp = distance0 / (distance0 - distance1);
-    o1.v = vIn[0].v + interp * (vIn[1].v - vIn[0].v);
-    o1.id.cf.indexA = (uint8_t)vertexIndexA;
-    o1.id.cf.indexB = vIn[0].id.cf.indexB;
-    o1.id.cf.typeA = kFeatureVertex;
-    o1.id.cf.typeB = kFeatureFace;
-    ++numOut;
+// one b2ClipSegmentToLine (b2Collision.cpp) on scalar clip vertices (p0, k0), (p1, k1), in place; returns the number of output
+// points.  When the segment crosses the line exactly one end is inside and the interpolated vertex becomes output 1; when both
+// are inside the output is the input - the selection upstream's `vOut[numOut++] = ...` sequence makes, without indexed stores.
+BLCD_HD static inline int ClipPair(Vec2& p0, uint32_t& k0, Vec2& p1, uint32_t& k1, Vec2 normal, float offset, int vertexIndexA) {
+  const float s0 = Dot(normal, p0) - offset;
+  const float s1 = Dot(normal, p1) - offset;
+  int n = (s0 <= 0.0f ? 1 : 0) + (s1 <= 0.0f ? 1 : 0);
+  Vec2 q1 = p1;
+  uint32_t j1 = k1;
+  if (s0 * s1 < 0.0f) {
+    const float interp = s0 / (s0 - s1);
+    q1 = p0 + interp * (p1 - p0);
+    j1 = FeatureKey(vertexIndexA, (int)((k0 >> 8) & 0xffu), kFeatureVertex, kFeatureFace);
+    ++n;
   }
-  vOut[0] = o0;
-  vOut[1] = o1;
-  return numOut;
+  if (!(s0 <= 0.0f)) {
+    p0 = p1;
+    k0 = k1;
+  }
+  p1 = q1;
+  k1 = j1;
+  return n;
 }
 
-// b2CollideCircles (b2CollideCircle.cpp)
-BLCD_HD static inline void CollideCircles(Manifold* manifold, const Shape* circleA, const Transform& xfA, const Shape* circleB,
-                                  const Transform& xfB) {
-  manifold->pointCount = 0;
-  Vec2 pA = Mul(xfA, circleA->v[0]);
-  Vec2 pB = Mul(xfB, circleB->v[0]);
-  Vec2 d = pB - pA;
-  float distSqr = Dot(d, d);
-  float rA = circleA->radius, rB = circleB->radius;
-  float radius = rA + rB;
-  if (distSqr > radius * radius) return;
-  manifold->type = kManifoldCircles;
-  manifold->localPoint = circleA->v[0];
-  manifold->localNormal = V2(0.0f, 0.0f);
-  manifold->pointCount = 1;
-  manifold->points[0].localPoint = circleB->v[0];
-  manifold->points[0].id.key = 0;
+// (circle, circle): b2CollideCircles (b2CollideCircle.cpp)
+BLCD_HD static inline void CollideCircles(Manifold* m, const Shape* circleA, const Transform& xfA, const Shape* circleB, const Transform& xfB) {
+  m->pointCount = 0;
+  const Vec2 gap = Mul(xfB, circleB->v[0]) - Mul(xfA, circleA->v[0]);
+  const float reach = circleA->radius + circleB->radius;
+  if (Dot(gap, gap) > reach * reach) return;
+  m->type = kManifoldCircles;
+  m->localNormal = V2(0.0f, 0.0f);
+  m->localPoint = circleA->v[0];
+  m->points[0].localPoint = circleB->v[0];
+  m->points[0].id.key = 0;
+  m->pointCount = 1;
 }
 
-// b2CollidePolygonAndCircle (b2CollideCircle.cpp)
-BLCD_HD static inline void CollidePolygonAndCircle(Manifold* manifold, const Shape* polygonA, const Transform& xfA,
-                                           const Shape* circleB, const Transform& xfB) {
-  manifold->pointCount = 0;
-  Vec2 c = Mul(xfB, circleB->v[0]);
-  Vec2 cLocal = MulT(xfA, c);
-  int normalIndex = 0;
-  float separation = -kMaxFloat;
-  float radius = polygonA->radius + circleB->radius;
-  int vertexCount = polygonA->count;
-  const Vec2* vertices = polygonA->v;
-  const Vec2* normals = polygonA->n;
-  for (int i = 0; i < vertexCount; ++i) {
-    float s = Dot(normals[i], cLocal - vertices[i]);
-    if (s > radius) return;
-    if (s > separation) {
-      separation = s;
-      normalIndex = i;
+// (polygon, circle): b2CollidePolygonAndCircle (b2CollideCircle.cpp).  The face of deepest penetration is found first (a face
+// that separates outright ends the routine); then the circle centre is in one of four situations - inside the polygon, beyond
+// the face's first or second vertex, or over the face - each of which yields (normal, point) for the same one-point manifold.
+BLCD_HD static inline void CollidePolygonAndCircle(Manifold* m, const Shape* polygonA, const Transform& xfA, const Shape* circleB,
+                                                   const Transform& xfB) {
+  m->pointCount = 0;
+  const Vec2 centre = MulT(xfA, Mul(xfB, circleB->v[0]));   // the circle in the polygon's frame
+  const float reach = polygonA->radius + circleB->radius;
+  const int count = polygonA->count;
+  int face = 0;
+  float deepest = -kMaxFloat;
+  for (int i = 0; i < count; ++i) {
+    const float s = Dot(polygonA->n[i], centre - polygonA->v[i]);
+    if (s > reach) return;
+    if (s > deepest) {
+      deepest = s;
+      face = i;
     }
   }
-  int vertIndex1 = normalIndex;
-  int vertIndex2 = vertIndex1 + 1 < vertexCount ? vertIndex1 + 1 : 0;
-  Vec2 v1 = vertices[vertIndex1];
-  Vec2 v2 = vertices[vertIndex2];
-  if (separation < kEpsilon) {
-    manifold->pointCount = 1;
-    manifold->type = kManifoldFaceA;
-    manifold->localNormal = normals[normalIndex];
-    manifold->localPoint = 0.5f * (v1 + v2);
-    manifold->points[0].localPoint = circleB->v[0];
-    manifold->points[0].id.key = 0;
-    return;
-  }
-  float u1 = Dot(cLocal - v1, v2 - v1);
-  float u2 = Dot(cLocal - v2, v1 - v2);
-  if (u1 <= 0.0f) {
-    if (DistanceSquared(cLocal, v1) > radius * radius) return;
-    manifold->pointCount = 1;
-    manifold->type = kManifoldFaceA;
-    manifold->localNormal = cLocal - v1;
-    Normalize(manifold->localNormal);
-    manifold->localPoint = v1;
-    manifold->points[0].localPoint = circleB->v[0];
-    manifold->points[0].id.key = 0;
-  } else if (u2 <= 0.0f) {
-    if (DistanceSquared(cLocal, v2) > radius * radius) return;
-    manifold->pointCount = 1;
-    manifold->type = kManifoldFaceA;
-    manifold->localNormal = cLocal - v2;
-    Normalize(manifold->localNormal);
-    manifold->localPoint = v2;
-    manifold->points[0].localPoint = circleB->v[0];
-    manifold->points[0].id.key = 0;
+  const Vec2 v1 = polygonA->v[face], v2 = polygonA->v[face + 1 < count ? face + 1 : 0];
+  const Vec2 faceN = polygonA->n[face];
+  Vec2 normal, point;
+  if (deepest < kEpsilon) {
+    normal = faceN;
+    point = 0.5f * (v1 + v2);
   } else {
-    Vec2 faceCenter = 0.5f * (v1 + v2);
-    float sep = Dot(cLocal - faceCenter, normals[vertIndex1]);
-    if (sep > radius) return;
-    manifold->pointCount = 1;
-    manifold->type = kManifoldFaceA;
-    manifold->localNormal = normals[vertIndex1];
-    manifold->localPoint = faceCenter;
-    manifold->points[0].localPoint = circleB->v[0];
-    manifold->points[0].id.key = 0;
+    const float u1 = Dot(centre - v1, v2 - v1);
+    const float u2 = Dot(centre - v2, v1 - v2);
+    if (u1 <= 0.0f || u2 <= 0.0f) {
+      const Vec2 corner = u1 <= 0.0f ? v1 : v2;
+      if (DistanceSquared(centre, corner) > reach * reach) return;
+      normal = centre - corner;
+      Normalize(normal);
+      point = corner;
+    } else {
+      const Vec2 mid = 0.5f * (v1 + v2);
+      if (Dot(centre - mid, faceN) > reach) return;
+      normal = faceN;
+      point = mid;
+    }
   }
+  m->pointCount = 1;
+  m->type = kManifoldFaceA;
+  m->localNormal = normal;
+  m->localPoint = point;
+  m->points[0].localPoint = circleB->v[0];
+  m->points[0].id.key = 0;
 }
 
 // b2FindMaxSeparation + b2EdgeSeparation (b2CollidePolygon.cpp, Box2D 2.3.0): separation of poly2 from edge e of poly1 =
@@ -507,121 +468,68 @@ BLCD_HD static inline float FindMaxSeparation(int* edgeIndex, const Shape* poly1
   return bestSep;
 }
 
-// b2FindIncidentEdge (b2CollidePolygon.cpp)
-BLCD_HD static inline void FindIncidentEdge(ClipVertex c[2], const Shape* poly1, const Transform& xf1, int edge1, const Shape* poly2,
-                                    const Transform& xf2) {
-  const Vec2* normals1 = poly1->n;
-  int count2 = poly2->count;
-  const Vec2* vertices2 = poly2->v;
-  const Vec2* normals2 = poly2->n;
-  Vec2 normal1 = MulT(xf2.q, Mul(xf1.q, normals1[edge1]));
-  int index = 0;
-  float minDot = kMaxFloat;
+// (polygon, polygon): b2CollidePolygons (b2CollidePolygon.cpp, Box2D 2.3.0 reference-face rule).  Polygon 1 carries the
+// reference face, polygon 2 the incident edge (b2FindIncidentEdge: the face of 2 most anti-parallel to the reference normal);
+// the incident edge is clipped against the side planes of the reference face and what stays within reach becomes the manifold.
+BLCD_HD static inline void CollidePolygons(Manifold* m, const Shape* polyA, const Transform& xfA, const Shape* polyB, const Transform& xfB) {
+  m->pointCount = 0;
+  const float reach = polyA->radius + polyB->radius;
+  int edgeA = 0, edgeB = 0;
+  const float sepA = FindMaxSeparation(&edgeA, polyA, xfA, polyB, xfB);
+  if (sepA > reach) return;
+  const float sepB = FindMaxSeparation(&edgeB, polyB, xfB, polyA, xfA);
+  if (sepB > reach) return;
+  const bool refIsB = sepB > 0.98f * sepA + 0.001f;   // k_relativeTol, k_absoluteTol
+  const Shape* poly1 = refIsB ? polyB : polyA;
+  const Shape* poly2 = refIsB ? polyA : polyB;
+  const Transform xf1 = PickXf(refIsB, xfB, xfA), xf2 = PickXf(refIsB, xfA, xfB);
+  const int e1 = refIsB ? edgeB : edgeA;
+  m->type = refIsB ? kManifoldFaceB : kManifoldFaceA;
+  // incident edge
+  const Vec2 refNormalIn2 = MulT(xf2.q, Mul(xf1.q, poly1->n[e1]));
+  const int count2 = poly2->count;
+  int inc = 0;
+  float least = kMaxFloat;
   for (int i = 0; i < count2; ++i) {
-    float dot = Dot(normal1, normals2[i]);
-    if (dot < minDot) {
-      minDot = dot;
-      index = i;
+    const float d = Dot(refNormalIn2, poly2->n[i]);
+    if (d < least) {
+      least = d;
+      inc = i;
     }
   }
-  int i1 = index;
-  int i2 = i1 + 1 < count2 ? i1 + 1 : 0;
-  c[0].v = Mul(xf2, vertices2[i1]);
-  c[0].id.cf.indexA = (uint8_t)edge1;
-  c[0].id.cf.indexB = (uint8_t)i1;
-  c[0].id.cf.typeA = kFeatureFace;
-  c[0].id.cf.typeB = kFeatureVertex;
-  c[1].v = Mul(xf2, vertices2[i2]);
-  c[1].id.cf.indexA = (uint8_t)edge1;
-  c[1].id.cf.indexB = (uint8_t)i2;
-  c[1].id.cf.typeA = kFeatureFace;
-  c[1].id.cf.typeB = kFeatureVertex;
-}
-
-// b2CollidePolygons (b2CollidePolygon.cpp)
-BLCD_HD static inline void CollidePolygons(Manifold* manifold, const Shape* polyA, const Transform& xfA, const Shape* polyB,
-                                   const Transform& xfB) {
-  manifold->pointCount = 0;
-  float totalRadius = polyA->radius + polyB->radius;
-  int edgeA = 0;
-  float separationA = FindMaxSeparation(&edgeA, polyA, xfA, polyB, xfB);
-  if (separationA > totalRadius) return;
-  int edgeB = 0;
-  float separationB = FindMaxSeparation(&edgeB, polyB, xfB, polyA, xfA);
-  if (separationB > totalRadius) return;
-
-  const Shape* poly1;
-  const Shape* poly2;
-  Transform xf1, xf2;
-  int edge1;
-  uint8_t flip;
-  if (separationB > 0.98f * separationA + 0.001f) {   // Box2D 2.3.0: k_relativeTol, k_absoluteTol
-    poly1 = polyB;
-    poly2 = polyA;
-    xf1 = xfB;
-    xf2 = xfA;
-    edge1 = edgeB;
-    manifold->type = kManifoldFaceB;
-    flip = 1;
-  } else {
-    poly1 = polyA;
-    poly2 = polyB;
-    xf1 = xfA;
-    xf2 = xfB;
-    edge1 = edgeA;
-    manifold->type = kManifoldFaceA;
-    flip = 0;
-  }
-  ClipVertex incidentEdge[2];
-  FindIncidentEdge(incidentEdge, poly1, xf1, edge1, poly2, xf2);
-  int count1 = poly1->count;
-  const Vec2* vertices1 = poly1->v;
-  int iv1 = edge1;
-  int iv2 = edge1 + 1 < count1 ? edge1 + 1 : 0;
-  Vec2 v11 = vertices1[iv1];
-  Vec2 v12 = vertices1[iv2];
-  Vec2 localTangent = v12 - v11;
+  const int inc2 = inc + 1 < count2 ? inc + 1 : 0;
+  Vec2 c0 = Mul(xf2, poly2->v[inc]), c1 = Mul(xf2, poly2->v[inc2]);
+  uint32_t k0 = FeatureKey(e1, inc, kFeatureFace, kFeatureVertex), k1 = FeatureKey(e1, inc2, kFeatureFace, kFeatureVertex);
+  // reference face
+  const int count1 = poly1->count;
+  const int e2 = e1 + 1 < count1 ? e1 + 1 : 0;
+  const Vec2 a1 = poly1->v[e1], a2 = poly1->v[e2];
+  Vec2 localTangent = a2 - a1;
   Normalize(localTangent);
-  Vec2 localNormal = Cross(localTangent, 1.0f);
-  Vec2 planePoint = 0.5f * (v11 + v12);
-  Vec2 tangent = Mul(xf1.q, localTangent);
-  Vec2 normal = Cross(tangent, 1.0f);
-  v11 = Mul(xf1, v11);
-  v12 = Mul(xf1, v12);
-  float frontOffset = Dot(normal, v11);
-  float sideOffset1 = -Dot(tangent, v11) + totalRadius;
-  float sideOffset2 = Dot(tangent, v12) + totalRadius;
-  ClipVertex clipPoints1[2];
-  ClipVertex clipPoints2[2];
-  int np;
-  np = ClipSegmentToLine(clipPoints1, incidentEdge, -tangent, sideOffset1, iv1);
-  if (np < 2) return;
-  np = ClipSegmentToLine(clipPoints2, clipPoints1, tangent, sideOffset2, iv2);
-  if (np < 2) return;
-  manifold->localNormal = localNormal;
-  manifold->localPoint = planePoint;
-  int pointCount = 0;
+  const Vec2 tangent = Mul(xf1.q, localTangent);
+  const Vec2 normal = Cross(tangent, 1.0f);
+  const Vec2 w1 = Mul(xf1, a1), w2 = Mul(xf1, a2);
+  const float frontOffset = Dot(normal, w1);
+  if (ClipPair(c0, k0, c1, k1, -tangent, -Dot(tangent, w1) + reach, e1) < 2) return;
+  if (ClipPair(c0, k0, c1, k1, tangent, Dot(tangent, w2) + reach, e2) < 2) return;
+  m->localNormal = Cross(localTangent, 1.0f);
+  m->localPoint = 0.5f * (a1 + a2);
+  int kept = 0;
 #pragma unroll
   for (int i = 0; i < kMaxManifoldPoints; ++i) {
-    float separation = Dot(normal, clipPoints2[i].v) - frontOffset;
-    if (separation <= totalRadius) {
+    const Vec2 c = i == 0 ? c0 : c1;
+    const uint32_t key = i == 0 ? k0 : k1;
+    if (Dot(normal, c) - frontOffset <= reach) {
       ManifoldPoint cp;
       cp.normalImpulse = 0.0f;
       cp.tangentImpulse = 0.0f;
-      cp.localPoint = MulT(xf2, clipPoints2[i].v);
-      cp.id = clipPoints2[i].id;
-      if (flip) {
-        ContactFeature cf = cp.id.cf;
-        cp.id.cf.indexA = cf.indexB;
-        cp.id.cf.indexB = cf.indexA;
-        cp.id.cf.typeA = cf.typeB;
-        cp.id.cf.typeB = cf.typeA;
-      }
-      PutManifoldPoint(manifold, pointCount, cp);
-      ++pointCount;
+      cp.localPoint = MulT(xf2, c);
+      cp.id.key = refIsB ? SwapFeatureSides(key) : key;
+      PutManifoldPoint(m, kept, cp);
+      ++kept;
     }
   }
-  manifold->pointCount = pointCount;
+  m->pointCount = kept;
 }
 
 // (wall, circle) and (wall, polygon) - b2CollideEdgeAndCircle, b2EPCollider - live in blcd_collide_wall.h

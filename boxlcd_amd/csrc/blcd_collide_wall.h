@@ -16,14 +16,6 @@
 
 namespace blcd {
 
-// b2ContactFeature as stored: indexA | indexB << 8 | typeA << 16 | typeB << 24
-BLCD_HD static inline uint32_t FeatureKey(int indexA, int indexB, int typeA, int typeB) {
-  return (uint32_t)(indexA & 0xff) | ((uint32_t)(indexB & 0xff) << 8) | ((uint32_t)typeA << 16) | ((uint32_t)typeB << 24);
-}
-BLCD_HD static inline uint32_t SwapFeatureSides(uint32_t k) {   // (indexA, typeA) <-> (indexB, typeB)
-  return ((k & 0x00ff00ffu) << 8) | ((k >> 8) & 0x00ff00ffu);
-}
-
 // What the two routines need to know about one wall (an edge from a to b with radius rad), as upstream computes it per call
 struct WallK {
   Vec2 a, b;       // m_vertex1, m_vertex2
@@ -85,30 +77,6 @@ BLCD_HD static inline void CollideWallCircle(Manifold* m, const WallK& w, Vec2 c
     m->localPoint = w.a;
     m->points[0].id.key = FeatureKey(0, 0, kFeatureFace, kFeatureVertex);
   }
-}
-
-// one b2ClipSegmentToLine on scalar clip vertices (p0, k0), (p1, k1) -> in place; returns the number of output points.
-// When the segment crosses the line exactly one end is inside and the interpolated vertex becomes output 1; when both are
-// inside the output is the input (the selection upstream's `vOut[numOut++] = ...` sequence makes).
-BLCD_HD static inline int ClipPair(Vec2& p0, uint32_t& k0, Vec2& p1, uint32_t& k1, Vec2 normal, float offset, int vertexIndexA) {
-  const float s0 = Dot(normal, p0) - offset;
-  const float s1 = Dot(normal, p1) - offset;
-  int n = (s0 <= 0.0f ? 1 : 0) + (s1 <= 0.0f ? 1 : 0);
-  Vec2 q1 = p1;
-  uint32_t j1 = k1;
-  if (s0 * s1 < 0.0f) {
-    const float interp = s0 / (s0 - s1);
-    q1 = p0 + interp * (p1 - p0);
-    j1 = FeatureKey(vertexIndexA, (int)((k0 >> 8) & 0xffu), kFeatureVertex, kFeatureFace);
-    ++n;
-  }
-  if (!(s0 <= 0.0f)) {
-    p0 = p1;
-    k0 = k1;
-  }
-  p1 = q1;
-  k1 = j1;
-  return n;
 }
 
 // (wall, polygon): b2EPCollider::Collide for an isolated edge (no adjacent vertices: lower/upper limit = -m_normal)
