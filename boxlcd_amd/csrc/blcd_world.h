@@ -2728,6 +2728,18 @@ struct Env {
     return false;
   }
 
+  // b2World::Step is the identity on an environment whose bodies are all asleep: b2ContactManager::Collide skips contacts without
+  // an active body, b2World::Solve seeds islands from awake bodies only (none: no velocity, position or sleep-timer update, no
+  // SynchronizeFixtures, an empty move buffer for FindNewContacts), b2World::SolveTOI skips contacts without an awake body.  Of
+  // the stored state only m_inv_dt0 is assigned, and it already holds this step's value once one step has been taken; a pending
+  // e_newFixture pass (right after a reset / state injection) is excluded.  Flag bits that a step toggles on the way
+  // (island / TOI marks) are not part of the stored state.
+  __device__ __forceinline__ bool atRest() const {
+    const float dt = S->dt;
+    const float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
+    return awakeMask == 0 && !(wflags & WF_NEWFIXTURE) && inv_dt0 == inv_dt && fault == 0;
+  }
+
   // action -> joint.motorSpeed (boxLCD/utils.py:117 mapto, world_env.py:441); b2RevoluteJoint::SetMotorSpeed wakes both bodies
   __device__ __forceinline__ void setMotorSpeeds(const float* __restrict__ actions, int N, int e) {
     const int nj = S->nj, nact = S->nact;
