@@ -61,7 +61,8 @@ def pmc_blocks(env_name, n_envs, dispatches_per_chunk=1):
         valu = {'valu_busy_frac_of_wave_cycles': c['SQ_ACTIVE_INST_VALU']['mean'] / w,
                 'waiting_frac_of_wave_cycles': c['SQ_WAIT_ANY']['mean'] / w if 'SQ_WAIT_ANY' in c else None,
                 'lanes_per_valu_inst': (c['SQ_THREAD_CYCLES_VALU']['mean'] / c['SQ_ACTIVE_INST_VALU']['mean']) if 'SQ_THREAD_CYCLES_VALU' in c else None,
-                'waves_per_dispatch': c['SQ_WAVES']['mean'] if 'SQ_WAVES' in c else None, 'waves_per_simd_limit': 1,
+                'waves_per_dispatch': c['SQ_WAVES']['mean'] if 'SQ_WAVES' in c else None,
+                'waves_per_simd_limit': 2 if '<1, 0, 4, 1,' in k else 1,   # register-bound: only the circles-only one-body kernel fits twice (212 VGPRs)
                 'source': f'{path} (rocprofv3 --pmc SQ_* pass of the same command; profile-derived)'}
       return traffic, src, valu
     except Exception:

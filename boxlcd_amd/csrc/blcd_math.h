@@ -124,13 +124,24 @@ BLCD_HD static BLCD_SINCOS_ATTR void blcd_sincosf(float y, float* sinp, float* c
 // ---------------------------------------------------------------------------------------------
 // b2Math.h restated
 // ---------------------------------------------------------------------------------------------
+// BLCD_VEC2_NATIVE makes Vec2 the compiler's own two-float vector: +, -, scalar * vector become element-wise built-ins (IEEE per
+// element, nothing contracted - the GPU suite stays bit-equal) and on gfx950 v_pk_add_f32 / v_pk_mul_f32 with the cross products'
+// swizzles in op_sel / neg modifiers: 14-18 % fewer VALU instructions in the solver loops of the (4,3,16) class.  Measured
+// (round 3): no gain - Bounce-100k -1.5 %, Dropbox-100k -4.5 %, Object2-200k -12 %, Urchin-50k 0 %, LuxoBall-50k -1 % - because
+// the even-aligned register pairs cost 30-50 more registers per kernel and more than twice the v_accvgpr traffic in the sweeps
+// (100 -> 232 per sweep).  The struct stays the default.
+#ifdef BLCD_VEC2_NATIVE
+typedef float Vec2 __attribute__((ext_vector_type(2)));
+#else
 struct Vec2 {
   float x, y;
 };
+#endif
 struct Vec3 {
   float x, y, z;
 };
 BLCD_HD static inline Vec2 V2(float x, float y) { return Vec2{x, y}; }
+#ifndef BLCD_VEC2_NATIVE
 BLCD_HD static inline Vec2 operator+(Vec2 a, Vec2 b) { return Vec2{a.x + b.x, a.y + b.y}; }
 BLCD_HD static inline Vec2 operator-(Vec2 a, Vec2 b) { return Vec2{a.x - b.x, a.y - b.y}; }
 BLCD_HD static inline Vec2 operator-(Vec2 a) { return Vec2{-a.x, -a.y}; }
@@ -147,6 +158,7 @@ BLCD_HD static inline void operator*=(Vec2& a, float s) {
   a.x *= s;
   a.y *= s;
 }
+#endif
 BLCD_HD static inline float Dot(Vec2 a, Vec2 b) { return a.x * b.x + a.y * b.y; }
 BLCD_HD static inline float Cross(Vec2 a, Vec2 b) { return a.x * b.y - a.y * b.x; }
 BLCD_HD static inline Vec2 Cross(Vec2 a, float s) { return Vec2{s * a.y, -s * a.x}; }
