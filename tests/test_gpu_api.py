@@ -310,3 +310,45 @@ def test_device_reset_sampler_equals_its_host_mirror(name):
   _, _, _, ost = pyb2o.rollout(env.scene.desc, pm[sub], sm[sub], acts[:, sub], 5, threads=4)
   assert (ost == st[sub]).all()
   env.close()
+
+
+@pytest.mark.parametrize('name,n', [('Dropbox', 1024), ('Dropbox', 200)])
+def test_environments_at_rest_reemit_identical_outputs(name, n):
+  """The general one-body class skips the world steps of an environment whose body is asleep and re-emits the frame rows /
+  observation row it computed a step earlier (step_kernel).  A fused rollout long enough for most boxes to fall
+  asleep - in waves that mix sleeping and moving environments, full (1024) and ragged (200) - must equal the unfused path (one
+  blcd_step + blcd_get_obs per env-step: no reuse there) frame for frame, observation for observation and in its final state,
+  for uint8 frames, 1-bit frames, and with either output missing."""
+  T = 150
+  env = B.BatchedWorldEnv(name, n, seed=5)
+  poses, sel = env.sample_initial(n)
+  d = env.scene.desc
+  h = Handle(d, n, 0)
+  h.reset(None, poses, sel)
+  ref_lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+  ref_obs = np.zeros((T, n, d.n_obs), np.float32)
+  for t in range(T):
+    h.step(None, 1)
+    fs, lcd = h.get_obs(np.float32)
+    ref_obs[t], ref_lcd[t] = fs, lcd
+  ref_state = h.debug_dump()[0].copy()
+  asleep = ref_state[:, 0, 7] == 0.0
+  assert asleep.mean() > 0.5     # the boxes fall asleep one by one during the rollout: sleeping and moving environments share waves on the way
+  h.close()
+  for variant in ('u8', 'bits', 'lcd_only', 'obs_only'):
+    h = Handle(d, n, 0)
+    h.reset(None, poses, sel)
+    obs = np.zeros((T, n, d.n_obs), np.float32) if variant != 'lcd_only' else None
+    if variant == 'bits':
+      lcd = np.zeros((T, n, d.lcd_h, d.lcd_w // 8), np.uint8)
+      h.rollout_bits(None, T, lcd, obs)
+      lcd = np.unpackbits(lcd, axis=-1, bitorder='little')
+    else:
+      lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8) if variant != 'obs_only' else None
+      h.rollout(None, T, lcd, obs)
+    if lcd is not None:
+      assert (lcd == ref_lcd).all(), variant
+    if obs is not None:
+      assert (obs == ref_obs).all(), variant
+    assert (h.debug_dump()[0] == ref_state).all(), variant
+    h.close()
