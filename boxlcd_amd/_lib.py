@@ -47,6 +47,7 @@ SYMBOLS = {
     'blcd_debug_dump': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'blcd_debug_sincos': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_debug_mass_data': (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.c_float, C.c_void_p]),
+    'blcd_debug_collide': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1854,6 +1854,107 @@ int blcd_debug_sincos(const float* x, int64_t n, float* s, float* c, int32_t dev
   return BLCD_OK;
 }
 
+// The narrow phase by itself: n independent (shape A, pose A, shape B, pose B) configurations through the DEVICE routines, dispatched
+// like b2Contact's s_registers.  tests/test_gpu_parity.py compares the manifolds bit for bit with the oracle's generic routines on
+// tens of thousands of random near-contact configurations - branches (vertex regions, polygon reference faces, clipped points)
+// that rollouts visit rarely.  An edge stands for an arena wall: its body must sit at the origin with angle 0 (what
+// blcd_collide_wall.h is written for).
+struct CollideCase {
+  Shape a, b;
+  Transform xa, xb;
+  int swapped;
+};
+__global__ void collide_kernel(const CollideCase* __restrict__ cases, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const CollideCase& c = cases[i];
+  Manifold m;
+  m.pointCount = 0;
+  m.type = 0;
+  m.localNormal = m.localPoint = V2(0.0f, 0.0f);
+  for (int j = 0; j < 2; ++j) {
+    m.points[j].localPoint = V2(0.0f, 0.0f);
+    m.points[j].normalImpulse = m.points[j].tangentImpulse = 0.0f;
+    m.points[j].id.key = 0;
+  }
+  if (c.a.type == kCircle) CollideCircles(&m, &c.a, c.xa, &c.b, c.xb);
+  else if (c.a.type == kPolygon && c.b.type == kCircle) CollidePolygonAndCircle(&m, &c.a, c.xa, &c.b, c.xb);
+  else if (c.a.type == kPolygon) CollidePolygons(&m, &c.a, c.xa, &c.b, c.xb);
+  else {
+    const WallK w = MakeWallK(c.a.v[0], c.a.v[1], c.a.radius);
+    if (c.b.type == kCircle) CollideWallCircle(&m, w, c.b.v[0], c.b.radius, c.xb);
+    else CollideWallPolygon(&m, w, &c.b, c.xb);
+  }
+  float* o = out + (size_t)i * 24;
+  for (int k = 0; k < 24; ++k) o[k] = 0.0f;
+  o[0] = (float)m.pointCount;
+  o[1] = (float)m.type;
+  o[2] = m.localNormal.x; o[3] = m.localNormal.y; o[4] = m.localPoint.x; o[5] = m.localPoint.y;
+  for (int j = 0; j < m.pointCount && j < 2; ++j) {
+    o[6 + 3 * j] = m.points[j].localPoint.x; o[7 + 3 * j] = m.points[j].localPoint.y; o[8 + 3 * j] = (float)m.points[j].id.key;
+  }
+  if (m.pointCount > 0) {
+    WorldManifold wm;
+    wm.Initialize(&m, c.xa, c.a.radius, c.xb, c.b.radius);
+    o[12] = wm.normal.x; o[13] = wm.normal.y;
+    for (int j = 0; j < m.pointCount && j < 2; ++j) {
+      o[14 + 3 * j] = wm.points[j].x; o[15 + 3 * j] = wm.points[j].y;   // [16 + 3 j]: separation, not computed by the product
+    }
+  }
+  o[20] = (float)c.swapped;
+}
+static bool shape_from_spec(const float* sp, Shape* s) {   // {0, r} circle | {1, hx, hy} box | {2, x1, y1, x2, y2} edge | {3, n, x0, y0, ...} polygon
+  const int kind = (int)sp[0];
+  *s = Shape{};
+  if (kind == 0) ShapeSetCircle(s, sp[1]);
+  else if (kind == 1) ShapeSetAsBox(s, sp[1], sp[2]);
+  else if (kind == 2) ShapeSetEdge(s, V2(sp[1], sp[2]), V2(sp[3], sp[4]));
+  else if (kind == 3 && (int)sp[1] >= 3 && (int)sp[1] <= kShapeVerts) {
+    Vec2 vs[kShapeVerts];
+    const int nv = (int)sp[1];
+    for (int i = 0; i < nv; ++i) vs[i] = V2(sp[2 + 2 * i], sp[3 + 2 * i]);
+    ShapeSetPolygon(s, vs, nv);
+  } else {
+    return false;
+  }
+  return true;
+}
+int blcd_debug_collide(int32_t device, int32_t n, const float* specA, const float* poseA, const float* specB, const float* poseB, float* out) {
+  if (n < 1 || !specA || !poseA || !specB || !poseB || !out) return fail(BLCD_ERR_INVALID, "blcd_debug_collide: bad arguments");
+  if (blcd_device_count() <= 0) return fail(BLCD_ERR_NO_DEVICE, "no HIP device available");
+  std::vector<CollideCase> cases((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    CollideCase& c = cases[(size_t)i];
+    if (!shape_from_spec(specA + (size_t)i * BLCD_COLLIDE_SPEC_FLOATS, &c.a) || !shape_from_spec(specB + (size_t)i * BLCD_COLLIDE_SPEC_FLOATS, &c.b))
+      return fail(BLCD_ERR_INVALID, "blcd_debug_collide: malformed shape spec");
+    c.xa.p = V2(poseA[3 * i], poseA[3 * i + 1]);
+    c.xa.q.Set(poseA[3 * i + 2]);
+    c.xb.p = V2(poseB[3 * i], poseB[3 * i + 1]);
+    c.xb.q.Set(poseB[3 * i + 2]);
+    auto rank = [](const Shape& s) { return s.type == kEdge ? 0 : (s.type == kPolygon ? 1 : 2); };
+    c.swapped = 0;
+    if (rank(c.a) > rank(c.b)) {
+      std::swap(c.a, c.b);
+      std::swap(c.xa, c.xb);
+      c.swapped = 1;
+    }
+    if (c.a.type == kEdge && (c.b.type == kEdge || c.xa.p.x != 0.0f || c.xa.p.y != 0.0f || c.xa.q.s != 0.0f || c.xa.q.c != 1.0f))
+      return fail(BLCD_ERR_UNSUPPORTED, "blcd_debug_collide: an edge is an arena wall - its body sits at the origin with angle 0, and walls do not meet walls");
+  }
+  HIPCHK(hipSetDevice(device));
+  CollideCase* dCases = nullptr;
+  float* dOut = nullptr;
+  HIPCHK(hipMalloc((void**)&dCases, (size_t)n * sizeof(CollideCase)));
+  HIPCHK(hipMalloc((void**)&dOut, (size_t)n * 24 * sizeof(float)));
+  HIPCHK(hipMemcpy(dCases, cases.data(), (size_t)n * sizeof(CollideCase), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(collide_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, (const CollideCase*)dCases, (int)n, dOut);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dOut, (size_t)n * 24 * sizeof(float), hipMemcpyDeviceToHost));
+  (void)hipFree(dCases);
+  (void)hipFree(dOut);
+  return BLCD_OK;
+}
+
 int blcd_debug_mass_data(const blcd_scene_desc* scene, int32_t shape, float density, float* out) {
   if (!scene || !out || shape < 0 || shape >= scene->n_shapes) return fail(BLCD_ERR_INVALID, "blcd_debug_mass_data: bad arguments");
   Shape s = build_shape(scene->shapes[shape]);

@@ -251,6 +251,13 @@ int blcd_debug_set_motor_speeds(blcd_handle h, const float* actions);       /* t
 int blcd_debug_dump(blcd_handle h, float* bodies, float* joints, float* pairs); /* host [n_envs][..][FLOATS] */
 int blcd_debug_sincos(const float* x, int64_t n, float* s, float* c, int32_t device); /* device sincosf on host arrays */
 int blcd_debug_mass_data(const blcd_scene_desc* scene, int32_t shape, float density, float* out16);
+/* The device narrow phase by itself (b2CollideCircles / b2CollidePolygonAndCircle / b2CollidePolygons and the wall forms of
+ * b2CollideEdgeAndCircle / b2EPCollider), n independent configurations, host arrays.  spec[n][BLCD_COLLIDE_SPEC_FLOATS] =
+ * {0, r} circle | {1, hx, hy} box | {2, x1, y1, x2, y2} edge (its pose must be 0, 0, 0) | {3, k, x0, y0, ...} polygon (k <= 8);
+ * pose[n][3] = x, y, angle; out[n][24] = pointCount, type, localNormal.xy, localPoint.xy, {localPoint.xy, id.key} x 2,
+ * world normal.xy, {world point.xy, -} x 2, swapped (A and B exchanged as b2Contact::Create does).  Test hook. */
+#define BLCD_COLLIDE_SPEC_FLOATS 18
+int blcd_debug_collide(int32_t device, int32_t n, const float* specA, const float* poseA, const float* specB, const float* poseB, float* out);
 
 #ifdef __cplusplus
 }

@@ -444,3 +444,92 @@ def test_two_wave_widths_change_nothing(monkeypatch, name, n):
   assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
   for x, y in zip(res[0][2], res[1][2]):
     assert (x == y).all()
+
+
+def _random_convex(rng, k, r0, r1):
+  """k points on a jittered circle, CCW: a convex polygon b2PolygonShape::Set keeps as it is (up to its own vertex order)"""
+  ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+  while np.diff(np.concatenate([ang, [ang[0] + 2 * np.pi]])).min() < 0.25:
+    ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+  r = rng.uniform(r0, r1)
+  return np.stack([r * np.cos(ang), r * np.sin(ang)], 1)
+
+
+def _shape_spec(rng, kind):
+  sp = np.zeros(34, np.float32)
+  if kind == 'circle':
+    sp[:2] = [0, rng.uniform(0.2, 0.8)]
+    reach = sp[1]
+  elif kind == 'box':
+    sp[:3] = [1, rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8)]
+    reach = float(np.hypot(sp[1], sp[2]))
+  else:
+    k = int(kind[4:])
+    v = _random_convex(rng, k, 0.3, 0.8)
+    sp[0], sp[1] = 3, k
+    sp[2:2 + 2 * k] = v.reshape(-1)
+    reach = float(np.abs(v).max())
+  return sp, reach
+
+
+@pytest.mark.parametrize('pair', ['circle-circle', 'box-circle', 'poly5-circle', 'box-box', 'poly6-box', 'poly8-poly5', 'wall-circle', 'wall-box',
+                                  'wall-poly7', 'edge-circle', 'edge-poly6'])
+def test_device_narrow_phase_equals_the_oracle_on_random_configurations(pair):
+  """The product's narrow phase (wall-specialised edge routines with host-built per-wall constants, rewritten body-body routines,
+  its own world-manifold code) against the oracle's upstream-shaped generic routines, manifold by manifold and bit for bit, on
+  8 000 random near-contact configurations per shape pair - vertex regions, polygon reference faces, clipped and dropped points,
+  deep overlaps and near misses that a rollout visits rarely.  (The oracle's routines are themselves checked against geometry in
+  tests/test_oracle_narrowphase.py.)  'wall' = one of the arena's four edges, 'edge' = an arbitrary segment; both at pose 0."""
+  from boxlcd_amd import _lib
+  import ctypes as C
+  n = 8000
+  import zlib
+  rng = np.random.RandomState(zlib.crc32(pair.encode()))
+  ka, kb = pair.split('-')
+  SA, PA, SB, PB = np.zeros((n, 34), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 34), np.float32), np.zeros((n, 3), np.float32)
+  for i in range(n):
+    sb, rb = _shape_spec(rng, kb)
+    pb = np.array([rng.uniform(1, 4), rng.uniform(1, 4), rng.uniform(-3.2, 3.2)])
+    if ka in ('wall', 'edge'):
+      W, H = rng.choice([5.0, 7.5, 10.0]), 5.0
+      if ka == 'wall':
+        a, b = [((0, 0), (W, 0)), ((0, 0), (0, H)), ((W, 0), (W, H)), ((0, H), (W, H))][rng.randint(4)]
+      else:
+        a = rng.uniform(0, 5, 2)
+        th = rng.uniform(0, 2 * np.pi)
+        b = a + rng.uniform(1.0, 6.0) * np.array([np.cos(th), np.sin(th)])
+      a, b = np.asarray(a, float), np.asarray(b, float)
+      SA[i, :5] = [2, a[0], a[1], b[0], b[1]]
+      t = rng.uniform(-0.15, 1.15)                       # along the segment, a little beyond both ends (vertex regions)
+      e = (b - a) / np.linalg.norm(b - a)
+      nrm = np.array([-e[1], e[0]]) * rng.choice([-1.0, 1.0])
+      inner = min(sb[1], sb[2]) if kb == 'box' else (sb[1] if kb == 'circle' else 0.3)
+      dist = rng.uniform(0.5 * inner, rb + 0.03) if rng.rand() < 0.8 else rng.uniform(-0.05, rb + 0.08)
+      pb[:2] = a + t * (b - a) + dist * nrm
+    else:
+      sa, ra = _shape_spec(rng, ka)
+      SA[i] = sa
+      PA[i] = [rng.uniform(1, 4), rng.uniform(1, 4), rng.uniform(-3.2, 3.2)]
+      th = rng.uniform(0, 2 * np.pi)
+      dist = rng.uniform(0.4, 1.0) * (ra + rb) + rng.uniform(-0.03, 0.05)
+      pb[:2] = PA[i, :2] + dist * np.array([np.cos(th), np.sin(th)])
+    SB[i], PB[i] = sb, pb
+  out = np.zeros((n, 24), np.float32)
+  A18, B18 = np.ascontiguousarray(SA[:, :18]), np.ascontiguousarray(SB[:, :18])     # BLCD_COLLIDE_SPEC_FLOATS (polygons of up to 8 vertices)
+  _lib._check(_lib.load().blcd_debug_collide(0, n, _lib._ptr(A18), _lib._ptr(PA), _lib._ptr(B18), _lib._ptr(PB), _lib._ptr(out)))
+  olib = pyb2o.load()
+  olib.b2o_collide.restype = C.c_int32
+  ref = np.zeros((n, 24), np.float32)
+  for i in range(n):
+    assert olib.b2o_collide(pyb2o._p(SA[i]), pyb2o._p(PA[i]), pyb2o._p(SB[i]), pyb2o._p(PB[i]), pyb2o._p(ref[i])) >= 0
+  ref[:, [16, 19]] = 0.0                                 # the separations: the product's world-manifold code does not compute them
+  touching = ref[:, 0] > 0
+  ref[~touching, 2:6] = 0.0                              # without a contact the routines leave localNormal / localPoint as they found them
+  out[~touching, 2:6] = 0.0                              # (the oracle's hook hands them an uninitialised manifold)
+  assert 0.25 < touching.mean() < 0.98, touching.mean()  # the sample straddles the contact boundary
+  if kb != 'circle':
+    assert (ref[:, 0] == 2).mean() > 0.1 and (ref[:, 0] == 1).mean() > 0.01
+    assert (ref[touching, 1] == 2).mean() > 0.02         # polygon reference faces (e_faceB) occur
+  bad = np.nonzero((out.view(np.uint32) != ref.view(np.uint32)).any(1))[0]
+  # the manifold keys are floats holding integers; compare bit patterns so that signs of zeros count too
+  assert len(bad) == 0, (pair, len(bad), bad[:5], out[bad[:2]], ref[bad[:2]])
