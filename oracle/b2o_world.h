@@ -11,6 +11,8 @@
 // (dynamic lists, islands by DFS) and NOT like the HIP product (fixed pair slots, SoA).
 #pragma once
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 #include "b2o_toi.h"
@@ -129,6 +131,10 @@ struct ContactPositionConstraint {
   float radiusA, radiusB;
   int pointCount;
 };
+
+// diagnostic switches of the sweep trace (B2O_TRACE_NONE=<solves to print>): see World::IslandSolve
+inline int& traceLeft() { static int n = std::getenv("B2O_TRACE_NONE") ? std::atoi(std::getenv("B2O_TRACE_NONE")) : 0; return n; }
+inline bool traceOn() { static bool on = std::getenv("B2O_TRACE_NONE") != nullptr; return on; }
 
 struct Stats {
   long toiIters = 0;   // diagnostic: minimum-TOI contacts advanced to (true events + those that turn out not to touch)
@@ -1210,6 +1216,7 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
   int fixedAt = -1;
   std::vector<unsigned long long> hashes;
   int cyclePeriod = 0, cycleAt = -1;
+  std::vector<std::vector<float>> trace;
   for (int i = 0; i < step.velocityIterations; ++i) {
     std::vector<Velocity> v0;
     std::vector<ContactVelocityConstraint> c0;
@@ -1245,6 +1252,29 @@ inline void World::IslandSolve(std::vector<int>& ibodies, std::vector<int>& icon
       for (int pp = 1; pp <= 32 && pp <= (int)hashes.size(); ++pp)
         if (hashes[hashes.size() - pp] == hsh) { cyclePeriod = pp; cycleAt = i; break; }
       hashes.push_back(hsh);
+    }
+    if (stats.trackSweeps && traceOn()) {   // diagnostic (B2O_TRACE_NONE=1): the sweep states of solves that neither settle nor cycle
+      std::vector<float> row;
+      for (auto& vv : velocities) { row.push_back(vv.v.x); row.push_back(vv.v.y); row.push_back(vv.w); }
+      for (auto& cc : contactSolver.vcs) for (int q = 0; q < cc.pointCount; ++q) { row.push_back(cc.points[q].normalImpulse); row.push_back(cc.points[q].tangentImpulse); }
+      trace.push_back(row);
+    }
+  }
+  if (stats.trackSweeps && traceOn() && !trace.empty()) {   // one line per solve: first sweep from which the velocities never change again
+    const size_t nv = 3 * velocities.size();
+    int vfix = (int)trace.size() - 1;
+    while (vfix > 0 && std::equal(trace[vfix - 1].begin(), trace[vfix - 1].begin() + nv, trace.back().begin())) --vfix;
+    std::fprintf(stderr, "VFIX %d %d %d %d %d %d %d\n", (int)ijoints.size(), (int)icontacts.size(), (int)ibodies.size(), fixedAt, cyclePeriod, cycleAt, vfix);
+  }
+  if (stats.trackSweeps && traceOn() && ijoints.empty() && fixedAt < 0 && cyclePeriod == 0 && traceLeft() > 0 &&
+      !std::equal(trace[trace.size() - 2].begin(), trace[trace.size() - 2].begin() + 3 * velocities.size(), trace.back().begin())) {
+    --traceLeft();
+    std::fprintf(stderr, "TRACE nb=%d nc=%d\n", (int)ibodies.size(), (int)icontacts.size());
+    for (size_t i = 0; i < trace.size(); ++i) {
+      if (i >= 4 && i + 14 < trace.size() && i % 30 != 0) continue;
+      std::fprintf(stderr, " %3d:", (int)i);
+      for (float f : trace[i]) std::fprintf(stderr, " %a", f);
+      std::fprintf(stderr, "\n");
     }
   }
   if (stats.trackSweeps) { stats.periodHist[cyclePeriod == 0 ? 33 : cyclePeriod]++; if (cyclePeriod) { stats.cycleAtSum += cycleAt; stats.cycleCount++; } }
