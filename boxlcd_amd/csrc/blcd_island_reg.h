@@ -827,6 +827,9 @@ struct RegIsland {
   struct CycRow {
     float v[kCycW];
   };
+  struct CycDig {
+    uint32_t d;
+  };
   __device__ __forceinline__ void cycPack(CycRow& r) const {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -890,6 +893,7 @@ struct RegIsland {
 #endif
     const bool watch = nj == 0 && nc > 0;
     CycRow cyc[kCycP];
+    CycDig cycDig[kCycP];
     for (int it = startIt; it < velIters; ++it) {
       bool changed = false;
 #ifdef BLCD_PROF_TOI2
@@ -908,10 +912,17 @@ struct RegIsland {
       if (watch && it < 24) {
         CycRow cur;
         cycPack(cur);
+        // A digest of the row filters the candidates: the stored rows are fetched (a select chain per word) and compared word by
+        // word only where the digests agree, and the verdict is the word-by-word comparison's alone.  (+ 0.0f maps -0 to +0 like
+        // the float comparison does; 31 is odd, so no word's contribution is shifted out.)
+        uint32_t dig = 0;
+#pragma unroll
+        for (int q = 0; q < kCycW; ++q) dig = dig * 31u + __float_as_uint(cur.v[q] + 0.0f);
         bool found = false;
 #pragma unroll
         for (int p = 1; p <= kCycP; ++p) {
           if (found || p > it) continue;
+          if (rGet(cycDig, (it - p) & (kCycP - 1)).d != dig) continue;
           const CycRow old = rGet(cyc, (it - p) & (kCycP - 1));
           bool same = true;
 #pragma unroll
@@ -924,6 +935,7 @@ struct RegIsland {
         }
         if (found) break;
         rSet(cyc, it & (kCycP - 1), cur);
+        rSet(cycDig, it & (kCycP - 1), CycDig{dig});
       }
       if (yieldAt > 0 && it == yieldAt - 1 && velIters > yieldAt) {
         if (__popcll(__ballot(1)) <= yieldMaxLanes) {

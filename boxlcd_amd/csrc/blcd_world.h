@@ -1476,6 +1476,9 @@ struct Env {
   struct CycRow {
     float v[kCycW];
   };
+  struct CycDig {
+    uint32_t d;
+  };
   // static layout: body i at [3*i..3*i+2] (bodies outside the island stay 0), contact k at [3*kCycNB + 4*k ..]
   __device__ __forceinline__ void cycPack(uint32_t ibmask, int nic, CycRow& dst) const {
 #pragma unroll
@@ -1556,6 +1559,7 @@ struct Env {
     pinSweepConstants();
     bool watch = nij == 0 && nic > 0 && nic <= kCycNC && (ibmask >> kCycNB) == 0;
     CycRow cyc[kCycP];
+    CycDig cycDig[kCycP];
     for (int it = startIt; it < velIters; ++it) {
       bool changed = false;
       for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
@@ -1564,10 +1568,15 @@ struct Env {
       if (watch && it < kCycSweeps) {
         CycRow cur;
         cycPack(ibmask, nic, cur);
+        // digest filter: see RegIsland::velocitySweeps (blcd_island_reg.h) - rows are fetched and compared only where digests agree
+        uint32_t dig = 0;
+#pragma unroll
+        for (int q = 0; q < kCycW; ++q) dig = dig * 31u + __float_as_uint(cur.v[q] + 0.0f);
         bool found = false;
 #pragma unroll
         for (int p = 1; p <= kCycP; ++p) {
           if (found || p > it) continue;
+          if (selGet(cycDig, (it - p) & (kCycP - 1)).d != dig) continue;
           const CycRow old = selGet(cyc, (it - p) & (kCycP - 1));
           bool same = true;
 #pragma unroll
@@ -1580,6 +1589,7 @@ struct Env {
         }
         if (found) break;
         selSet(cyc, it & (kCycP - 1), cur);
+        selSet(cycDig, it & (kCycP - 1), CycDig{dig});
       }
       if (mayYield && it == kYieldSweeps - 1 && velIters > kYieldSweeps) {
         // the lanes that reach this line are the wave's stragglers (everyone else left the loop at a fixed point / short cycle)
