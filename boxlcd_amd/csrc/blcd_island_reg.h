@@ -892,8 +892,16 @@ struct RegIsland {
     }
 #endif
     const bool watch = nj == 0 && nc > 0;
+#ifndef BLCD_CYC_WINDOW
+    constexpr int kCycWatch = 48;
+    CycRow ref;
+    uint32_t refDig = 0;
+    int refIt = -1, last = velIters - 1;
+    bool cycling = false;
+#else
     CycRow cyc[kCycP];
     CycDig cycDig[kCycP];
+#endif
     for (int it = startIt; it < velIters; ++it) {
       bool changed = false;
 #ifdef BLCD_PROF_TOI2
@@ -909,6 +917,39 @@ struct RegIsland {
         if (k < nc) changed = sweepContact(k, ct[k]) || changed;
       ++done;
       if (!changed) break;
+#ifndef BLCD_CYC_WINDOW
+      // Short-cycle detection, Brent's way: ONE reference row (taken after sweeps 1, 2, 4, 8, 16, 32), a digest of every sweep's
+      // state compared with the reference's, the rows compared word by word only when the digests agree.  State(it) == state(ref)
+      // makes the sequence periodic with period p = it - ref from ref on, so the state after the last sweep is the state
+      // (velIters - 1 - it) mod p sweeps from here: the lane sweeps that many more times and stops.  Against the four-row window
+      // this replaced: no ring of rows behind select chains (the window cost 28 instructions per state word and
+      // sweep, then 7 with the digest; this costs 4), periods up to 16 and cycles that begin as late as sweep 32 are caught too;
+      // a cycle is noticed up to twice as late, and its tail is swept instead of restored.  Which sweeps are skipped is the only
+      // thing that changes: every exit still leaves exactly the state that all velIters sweeps would.
+      if (it >= last) break;
+      if (watch && !cycling && it < kCycWatch) {
+        CycRow cur;
+        cycPack(cur);
+        uint32_t dig = 0;      // + 0.0f maps -0 to +0 like the float comparison does; 31 is odd, so no word's contribution is shifted out
+#pragma unroll
+        for (int q = 0; q < kCycW; ++q) dig = dig * 31u + __float_as_uint(cur.v[q] + 0.0f);
+        if (refIt >= 0 && dig == refDig) {
+          bool same = true;
+#pragma unroll
+          for (int q = 0; q < kCycW; ++q) same = same && (ref.v[q] == cur.v[q]);
+          if (same) {
+            cycling = true;
+            last = it + (velIters - 1 - it) % (it - refIt);
+            if (last == it) break;
+          }
+        }
+        if (((it + 1) & it) == 0) {
+          ref = cur;
+          refDig = dig;
+          refIt = it;
+        }
+      }
+#else
       if (watch && it < 24) {
         CycRow cur;
         cycPack(cur);
@@ -937,6 +978,7 @@ struct RegIsland {
         rSet(cyc, it & (kCycP - 1), cur);
         rSet(cycDig, it & (kCycP - 1), CycDig{dig});
       }
+#endif
       if (yieldAt > 0 && it == yieldAt - 1 && velIters > yieldAt) {
         if (__popcll(__ballot(1)) <= yieldMaxLanes) {
           *yielded = true;

@@ -1558,13 +1558,47 @@ struct Env {
     const int velIters = S->velIters;
     pinSweepConstants();
     bool watch = nij == 0 && nic > 0 && nic <= kCycNC && (ibmask >> kCycNB) == 0;
+#ifndef BLCD_CYC_WINDOW
+    constexpr int kCycWatch = 48;
+    CycRow ref;
+    uint32_t refDig = 0;
+    int refIt = -1, last = velIters - 1;
+    bool cycling = false;
+#else
     CycRow cyc[kCycP];
     CycDig cycDig[kCycP];
+#endif
     for (int it = startIt; it < velIters; ++it) {
       bool changed = false;
       for (int k = 0; k < nij; ++k) changed = jointSolveVelocity(ij[k], h) || changed;
       changed = csSolveVelocityConstraints(nic) || changed;
       if (!changed) break;
+#ifndef BLCD_CYC_WINDOW
+      // Brent's cycle detection with one reference row and a digest per sweep: see RegIsland::velocitySweeps (blcd_island_reg.h)
+      if (it >= last) break;
+      if (watch && !cycling && it < kCycWatch) {
+        CycRow cur;
+        cycPack(ibmask, nic, cur);
+        uint32_t dig = 0;
+#pragma unroll
+        for (int q = 0; q < kCycW; ++q) dig = dig * 31u + __float_as_uint(cur.v[q] + 0.0f);
+        if (refIt >= 0 && dig == refDig) {
+          bool same = true;
+#pragma unroll
+          for (int q = 0; q < kCycW; ++q) same = same && (ref.v[q] == cur.v[q]);
+          if (same) {
+            cycling = true;
+            last = it + (velIters - 1 - it) % (it - refIt);
+            if (last == it) break;
+          }
+        }
+        if (((it + 1) & it) == 0) {
+          ref = cur;
+          refDig = dig;
+          refIt = it;
+        }
+      }
+#else
       if (watch && it < kCycSweeps) {
         CycRow cur;
         cycPack(ibmask, nic, cur);
@@ -1591,6 +1625,7 @@ struct Env {
         selSet(cyc, it & (kCycP - 1), cur);
         selSet(cycDig, it & (kCycP - 1), CycDig{dig});
       }
+#endif
       if (mayYield && it == kYieldSweeps - 1 && velIters > kYieldSweeps) {
         // the lanes that reach this line are the wave's stragglers (everyone else left the loop at a fixed point / short cycle)
         if (__popcll(__ballot(1)) <= yieldMaxLanes) return true;
