@@ -396,42 +396,56 @@ BLCD_HD static inline void CollidePolygonAndCircle(Manifold* m, const Shape* pol
 // climb that starts at the edge whose normal faces poly2's centroid.  The separation of an edge is a pure function of the
 // pose, so this kernel-side formulation evaluates all (<= 8) edges branch-free first - poly2's world vertices once - and
 // then replays the climb's decisions on that table; the oracle evaluates lazily like upstream.
+// Run-time indexed reads of the two small tables below are compile-time unrolled compare/selects (fold expressions): written as
+// loops they are re-rolled by LLVM into indexed loads, the tables then live in scratch, and every step of the climb becomes a
+// dependent ~450-cycle scratch load at one wave per SIMD.
+template <typename T, size_t... K>
+BLCD_HD static inline T pickOf8(const T (&a)[kShapeVerts], int i, std::index_sequence<K...>) {
+  T r = a[0];
+  ((r = (i == (int)(K + 1)) ? a[K + 1] : r), ...);
+  return r;
+}
 BLCD_HD static inline float FindMaxSeparation(int* edgeIndex, const Shape* poly1, const Transform& xf1, const Shape* poly2,
                                       const Transform& xf2) {
+  static_assert(kShapeVerts == 8, "pickOf8");
   const int count1 = poly1->count, count2 = poly2->count;
-  Vec2 w2[kShapeVerts];
-  for (int j = 0; j < kShapeVerts; ++j)
-    if (j < count2) w2[j] = Mul(xf2, poly2->v[j]);
+  float w2x[kShapeVerts], w2y[kShapeVerts], v2x[kShapeVerts], v2y[kShapeVerts];
+#pragma unroll
+  for (int j = 0; j < kShapeVerts; ++j) {
+    const Vec2 pv = poly2->v[j < count2 ? j : 0];
+    const Vec2 pw = Mul(xf2, pv);
+    v2x[j] = pv.x;
+    v2y[j] = pv.y;
+    w2x[j] = pw.x;
+    w2y[j] = pw.y;
+  }
   float sep[kShapeVerts];
+#pragma unroll
   for (int e = 0; e < kShapeVerts; ++e) {
+    sep[e] = 0.0f;
     if (e >= count1) continue;
     const Vec2 nW = Mul(xf1.q, poly1->n[e]);
     const Vec2 nL = MulT(xf2.q, nW);
     int support = 0;
     float lowest = kMaxFloat;
+#pragma unroll
     for (int j = 0; j < kShapeVerts; ++j) {
       if (j >= count2) continue;
-      const float d = Dot(poly2->v[j], nL);
+      const float d = Dot(V2(v2x[j], v2y[j]), nL);
       if (d < lowest) {
         lowest = d;
         support = j;
       }
     }
-    Vec2 far = w2[0];
-    for (int j = 1; j < kShapeVerts; ++j)
-      if (j == support) far = w2[j];
+    const Vec2 far = V2(pickOf8(w2x, support, std::make_index_sequence<kShapeVerts - 1>{}), pickOf8(w2y, support, std::make_index_sequence<kShapeVerts - 1>{}));
     sep[e] = Dot(far - Mul(xf1, poly1->v[e]), nW);
   }
-  auto at = [&](int e) {
-    float r = sep[0];
-    for (int k = 1; k < kShapeVerts; ++k)
-      if (k == e) r = sep[k];
-    return r;
-  };
+  auto at = [&](int e) { return pickOf8(sep, e, std::make_index_sequence<kShapeVerts - 1>{}); };
   // starting edge: normal with the largest projection on the centroid offset (poly1 frame)
   const Vec2 dLocal1 = MulT(xf1.q, Mul(xf2, poly2->centroid) - Mul(xf1, poly1->centroid));
   int edge = 0;
   float maxDot = -kMaxFloat;
+#pragma unroll
   for (int i = 0; i < kShapeVerts; ++i) {
     if (i >= count1) continue;
     const float dot = Dot(poly1->n[i], dLocal1);
