@@ -15,6 +15,7 @@
 // State lives SoA in HBM ([field][env], env fastest => coalesced 256 B lines per wave) and is staged into
 // per-thread storage for the duration of a launch.
 #pragma once
+#include <type_traits>
 #include <utility>
 #include "blcd_toi.h"
 #include "blcd_toi_wall.h"
@@ -173,6 +174,64 @@ __device__ __forceinline__ void selSet(T (&a)[N], int i, const T& v) {
   if constexpr (N <= 4) selSetImpl(a, i, v, std::make_index_sequence<N>{});
   else a[i] = v;
 }
+// Per-body state arrays of the small scene classes.  Most accesses have a compile-time index (unrolled loops over bodies), but the
+// TOI phase, the contact update and the island bookkeeping reach a body through a run-time index (bi(proxy)), and ONE such access
+// keeps the whole array - and with it every access - in scratch (~450 cycles per dependent load at one wave per SIMD).  For 2-4
+// bodies `arr[i]` therefore goes through the compare/select chains above (a proxy object, so the call sites keep their array
+// syntax; a constant index folds to a plain register); larger classes keep plain arrays.  Pure data movement.
+template <typename T, int N>
+struct SelArr {
+  T e[N];
+  struct Ref {
+    T (&e)[N];
+    int i;
+    __device__ __forceinline__ operator T() const { return selGet(e, i); }
+    __device__ __forceinline__ const Ref& operator=(const T& x) const {
+      selSet(e, i, x);
+      return *this;
+    }
+    __device__ __forceinline__ const Ref& operator=(const Ref& r) const {
+      const T x = r;
+      selSet(e, i, x);
+      return *this;
+    }
+    template <typename U>
+    __device__ __forceinline__ const Ref& operator+=(const U& x) const {
+      T t = selGet(e, i);
+      t += x;
+      selSet(e, i, t);
+      return *this;
+    }
+    template <typename U>
+    __device__ __forceinline__ const Ref& operator-=(const U& x) const {
+      T t = selGet(e, i);
+      t -= x;
+      selSet(e, i, t);
+      return *this;
+    }
+    template <typename U>
+    __device__ __forceinline__ const Ref& operator*=(const U& x) const {
+      T t = selGet(e, i);
+      t *= x;
+      selSet(e, i, t);
+      return *this;
+    }
+  };
+  __device__ __forceinline__ Ref operator[](int i) { return Ref{e, i}; }
+  __device__ __forceinline__ T operator[](int i) const { return selGet(e, i); }
+};
+template <typename T, int N>
+struct PlainArr {
+  T e[N];
+  __device__ __forceinline__ T& operator[](int i) { return e[i]; }
+  __device__ __forceinline__ const T& operator[](int i) const { return e[i]; }
+};
+#ifndef BLCD_BODY_SEL
+#define BLCD_BODY_SEL 1
+#endif
+template <typename T, int N>
+using BodyArr = std::conditional_t<(BLCD_BODY_SEL && N >= 2 && N <= 4), SelArr<T, N>, PlainArr<T, N>>;
+
 // Small integers (slot ids, flag bytes, counters) indexed with run-time values.  Up to 4 entries share one register; up to 32
 // are packed four to a word in (N+3)/4 registers and a run-time index becomes a compare/select over the WORDS plus a shift -
 // a byte array indexed at run time would live in scratch, and the contact-list loops (collide, island DFS, the TOI scan) read
@@ -280,14 +339,15 @@ struct Env {
   static constexpr int kUS = NP <= 4 ? NP : 1;        // unroll factor of the per-slot load/store loops
   const DevScene* S;
   // --- dynamic bodies ---
-  Vec2 c[NB], v[NB], c0[NB], xfp[NB];
-  float a[NB], w[NB], a0[NB], sleepTime[NB], alpha0[NB];
-  Rot q[NB];
-  AABB fat[NB];
-  int sel[NB];
+  BodyArr<Vec2, NB> c, v, c0, xfp;
+  BodyArr<float, NB> a, w, a0, sleepTime, alpha0;
+  BodyArr<Rot, NB> q;
+  BodyArr<AABB, NB> fat;
+  BodyArr<int, NB> sel;
+  BodyArr<int, NB> shapeIx;   // S->bodies[i].var[sel[i]].shape, read once per launch: shapeOf() is then ONE dependent global load, not two
   uint32_t awakeMask;
-  float invMass[NB], invI[NB];
-  Vec2 lc[NB];
+  BodyArr<float, NB> invMass, invI;
+  BodyArr<Vec2, NB> lc;
   // --- pair slots ---
   ByteVec<NP> wl;        // world contact list, newest first (slot ids)
   int nc;
@@ -478,20 +538,25 @@ struct Env {
       xfp[i] = V2(p[(size_t)9 * N], p[(size_t)10 * N]);
       sleepTime[i] = p[(size_t)11 * N];
       if (p[(size_t)12 * N] != 0.0f) awakeMask |= 1u << i;
-      fat[i].lo = V2(p[(size_t)13 * N], p[(size_t)14 * N]);
-      fat[i].hi = V2(p[(size_t)15 * N], p[(size_t)16 * N]);
+      {
+        AABB fb_;
+        fb_.lo = V2(p[(size_t)13 * N], p[(size_t)14 * N]);
+        fb_.hi = V2(p[(size_t)15 * N], p[(size_t)16 * N]);
+        fat[i] = fb_;
+      }
       sel[i] = __float_as_int(p[(size_t)17 * N]);
       alpha0[i] = 0.0f;
       const DevVariant& var = S->bodies[i].var[sel[i]];
       invMass[i] = var.invMass;
       invI[i] = var.invI;
       lc[i] = var.localCenter;
+      shapeIx[i] = var.shape;
       const Shape& shp = S->shapes[var.shape];
       if (kCirc) {
         crad[i] = shp.radius;
         cctr[i] = shp.v[0];
       }
-      if (shp.type == kCircle && shp.v[0].x == 0.0f && shp.v[0].y == 0.0f && lc[i].x == 0.0f && lc[i].y == 0.0f &&
+      if (shp.type == kCircle && shp.v[0].x == 0.0f && shp.v[0].y == 0.0f && var.localCenter.x == 0.0f && var.localCenter.y == 0.0f &&
           S->bodies[i].nJoints == 0)   // a joint anchor would make the rotation matter
         deadQ |= 16u << i;
       q[i] = rotFor(4 + i, a[i]);   // the stored rotation is itself only consumed by contact code (see rotFor)
@@ -554,23 +619,25 @@ struct Env {
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
       float* p = st + (size_t)(i * kBodyFields) * N + e;
-      p[0] = c[i].x;
-      p[(size_t)1 * N] = c[i].y;
+      const Vec2 c_ = c[i], v_ = v[i], c0_ = c0[i], xfp_ = xfp[i];
+      const AABB fat_ = fat[i];
+      p[0] = c_.x;
+      p[(size_t)1 * N] = c_.y;
       p[(size_t)2 * N] = a[i];
-      p[(size_t)3 * N] = v[i].x;
-      p[(size_t)4 * N] = v[i].y;
+      p[(size_t)3 * N] = v_.x;
+      p[(size_t)4 * N] = v_.y;
       p[(size_t)5 * N] = w[i];
-      p[(size_t)6 * N] = c0[i].x;
-      p[(size_t)7 * N] = c0[i].y;
+      p[(size_t)6 * N] = c0_.x;
+      p[(size_t)7 * N] = c0_.y;
       p[(size_t)8 * N] = a0[i];
-      p[(size_t)9 * N] = xfp[i].x;
-      p[(size_t)10 * N] = xfp[i].y;
+      p[(size_t)9 * N] = xfp_.x;
+      p[(size_t)10 * N] = xfp_.y;
       p[(size_t)11 * N] = sleepTime[i];
       p[(size_t)12 * N] = (awakeMask >> i) & 1 ? 1.0f : 0.0f;
-      p[(size_t)13 * N] = fat[i].lo.x;
-      p[(size_t)14 * N] = fat[i].lo.y;
-      p[(size_t)15 * N] = fat[i].hi.x;
-      p[(size_t)16 * N] = fat[i].hi.y;
+      p[(size_t)13 * N] = fat_.lo.x;
+      p[(size_t)14 * N] = fat_.lo.y;
+      p[(size_t)15 * N] = fat_.hi.x;
+      p[(size_t)16 * N] = fat_.hi.y;
       // sel is immutable during stepping
     }
     float* pp = st + (size_t)(nb * kBodyFields) * N + e;
@@ -679,8 +746,7 @@ struct Env {
   __device__ __forceinline__ int typeOf(int p) const { return p < 4 ? (int)kEdge : (kCirc ? (int)kCircle : (int)shapeOf(p)->type); }
   __device__ __forceinline__ const Shape* shapeOf(int p) const {
     if (p < 4) return &S->wallShape[p];
-    int i = bi(p);
-    return &S->shapes[S->bodies[i].var[sel[i]].shape];
+    return &S->shapes[shapeIx[bi(p)]];
   }
   __device__ __forceinline__ AABB fatOf(int p) const {
     // value selects on purpose: `cond ? global : member` would become a select of POINTERS, which makes the member's
@@ -748,7 +814,8 @@ struct Env {
     aabb.lo = Min(aabb1.lo, aabb2.lo);
     aabb.hi = Max(aabb1.hi, aabb2.hi);
     Vec2 displacement = xf2.p - xf1.p;
-    if (fat[i].Contains(aabb)) return;
+    const AABB fatOld_ = fat[i];
+    if (fatOld_.Contains(aabb)) return;
     AABB fb = aabb;
     Vec2 r = V2(kAabbExtension, kAabbExtension);
     fb.lo = fb.lo - r;
@@ -2805,7 +2872,8 @@ struct Env {
     const int nb = S->nb;
     for (int i = 0; i < NB; ++i) {
       if (i >= nb) break;
-      float t = c[i].x + c[i].y + a[i] + v[i].x + v[i].y + w[i];
+      const Vec2 cc_ = c[i], vv_ = v[i];
+      float t = cc_.x + cc_.y + a[i] + vv_.x + vv_.y + w[i];
       if (!(t == t) || Abs(t) > 3.0e38f) fault |= FAULT_NAN;
     }
   }
