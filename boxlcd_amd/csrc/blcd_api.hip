@@ -1047,6 +1047,10 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   // Bounce-100k 1.84e9 (20) -> 2.02e9 (50) -> 2.12e9 (100); Dropbox-100k 6.4e8 (20) -> 6.6e8 (40, 50) -> 6.4e8 (100).
   // Multi-body batches keep 20 (Object2-200k: 6.3e7 / 6.1e7 / 5.8e7 at 10 / 20 / 40).  Results do not depend on the chunking.
   if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 1) h->rolloutChunk = kCfgs[h->cfg].sh == 1 ? 100 : 50;
+  // The general two-body class after the cheaper cycle detection (round 3): Object2-200k 7.65e7 / 7.62e7 / 7.50e7 / 7.31e7 at
+  // 5 / 10 / 15 / 20 - its waves are so uneven (5 of 64 lanes busy on average) that regrouping them twice as often pays; the circles
+  // two-body class and the three-body class show no trend (Bounce2-100k, Object3-100k within noise or best at 20) and keep 20.
+  if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 2 && kCfgs[h->cfg].sh == 0) h->rolloutChunk = 10;
   if (h->hostScene.nb <= 7) {
     if (const char* ev = getenv("BLCD_ASYNC")) h->asyncBudget = atoi(ev) > 0 ? atoi(ev) : 0;
     if (h->asyncBudget > 0) {
