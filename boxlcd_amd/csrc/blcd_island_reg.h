@@ -949,6 +949,25 @@ struct RegIsland {
           refIt = it;
         }
       }
+#ifndef BLCD_NO_UNTRACKED_TAIL
+      if (it == kCycWatch - 1 && yieldAt == 0) {
+        // Whoever is still here after the watch window either owes the tail of a detected cycle (`last`) or is a straggler that
+        // will, with rare exceptions, run to the end: the rest is swept without the exits' bookkeeping (a lane that reaches a fixed
+        // point on the way just sweeps on - the exits only ever skipped no-op sweeps).
+        for (int it2 = it + 1; it2 <= last; ++it2) {
+          if constexpr (NJR > 0) {
+#pragma unroll
+            for (int k = 0; k < NJR; ++k)
+              if (k < nj) sweepJoint<false>(jt[k], dt);
+          }
+#pragma unroll
+          for (int k = 0; k < NCR; ++k)
+            if (k < nc) sweepContact<false>(k, ct[k]);
+          ++done;
+        }
+        break;
+      }
+#endif
 #else
       if (watch && it < 24) {
         CycRow cur;

@@ -1114,6 +1114,7 @@ struct Env {
   // Returns true iff some constraint applied a non-zero impulse in this sweep.  A sweep is a deterministic function of
   // (velocities, accumulated impulses); Box2D applies lambda = clamp(acc + d) - acc, so "no accumulator moved" means
   // every applied impulse was exactly zero and the state is a fixed point: all remaining sweeps are no-ops.
+  template <bool TRACK = true>   // TRACK = false: the caller does not look at the result (velocitySweeps' tail)
   __device__ __forceinline__ bool csSolveVelocityConstraints(int count) {
     bool changed = false;
 #pragma unroll kU
@@ -1142,7 +1143,7 @@ struct Env {
         float newImpulse = Clamp(vcp->tangentImpulse + lambda, -maxFriction, maxFriction);
         lambda = newImpulse - vcp->tangentImpulse;
         vcp->tangentImpulse = newImpulse;
-        changed = changed || (lambda != 0.0f);
+        if constexpr (TRACK) changed = changed || (lambda != 0.0f);
         Vec2 P = lambda * tangent;
         if constexpr (!kWallA) {
           vA -= mA * P;
@@ -1160,7 +1161,7 @@ struct Env {
         float newImpulse = Max(vcp->normalImpulse + lambda, 0.0f);
         lambda = newImpulse - vcp->normalImpulse;
         vcp->normalImpulse = newImpulse;
-        changed = changed || (lambda != 0.0f);
+        if constexpr (TRACK) changed = changed || (lambda != 0.0f);
         Vec2 P = lambda * normal;
         if constexpr (!kWallA) {
           vA -= mA * P;
@@ -1210,7 +1211,7 @@ struct Env {
         }
         if (solved) {
           Vec2 d = x - a_;
-          changed = changed || (d.x != 0.0f) || (d.y != 0.0f);
+          if constexpr (TRACK) changed = changed || (d.x != 0.0f) || (d.y != 0.0f);
           Vec2 P1 = d.x * normal;
           Vec2 P2 = d.y * normal;
           if constexpr (!kWallA) {
@@ -1674,6 +1675,11 @@ struct Env {
           refDig = dig;
           refIt = it;
         }
+      }
+      if (it == kCycWatch - 1 && !mayYield && nij == 0) {
+        // the rest without the exits' bookkeeping: see RegIsland::velocitySweeps
+        for (int it2 = it + 1; it2 <= last; ++it2) csSolveVelocityConstraints<false>(nic);
+        break;
       }
 #else
       if (watch && it < kCycSweeps) {
