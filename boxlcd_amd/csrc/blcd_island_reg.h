@@ -17,6 +17,12 @@
 
 namespace blcd {
 
+// sweeps during which the short-cycle detector of the joint-free islands watches (reference rows after sweeps 1, 2, 4, ..); afterwards the
+// sweeps run untracked (velocitySweeps)
+#ifndef BLCD_CYC_WATCH
+#define BLCD_CYC_WATCH 48
+#endif
+
 // always-select array access (compile-time unrolled word selects; see selGet in blcd_world.h for why not a loop)
 template <typename T, int N, size_t... K>
 __device__ __forceinline__ void rWordsGet(const T (&a)[N], int i, int t, uint32_t* r, std::index_sequence<K...>) {
@@ -893,7 +899,7 @@ struct RegIsland {
 #endif
     const bool watch = nj == 0 && nc > 0;
 #ifndef BLCD_CYC_WINDOW
-    constexpr int kCycWatch = 48;
+    constexpr int kCycWatch = BLCD_CYC_WATCH;
     CycRow ref;
     uint32_t refDig = 0;
     int refIt = -1, last = velIters - 1;

@@ -1637,7 +1637,7 @@ struct Env {
     pinSweepConstants();
     bool watch = nij == 0 && nic > 0 && nic <= kCycNC && (ibmask >> kCycNB) == 0;
 #ifndef BLCD_CYC_WINDOW
-    constexpr int kCycWatch = 48;
+    constexpr int kCycWatch = BLCD_CYC_WATCH;
     CycRow ref;
     uint32_t refDig = 0;
     int refIt = -1, last = velIters - 1;
