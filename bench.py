@@ -28,33 +28,53 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES = {'Dropbox': 564, 'Bounce': 564, 'Object2': 924, 'Urchin': 1836, 'LuxoBall': 2236}
+ALG_BYTES = {'Dropbox': 564, 'Bounce': 564, 'Object2': 924, 'Urchin': 1836, 'LuxoBall': 2236,
+             'Crab': 2 * (17 * 32 + 16 * 16 + 68 * 28) + 4 * 12 + 4 * 68 + 32 * 64}             # same rule (2 x state + 4 act + 4 obs + lcd bytes): 17 bodies, 16 joints, 68 wall pair slots, 32x64 LCD = 7776 B
 HBM_PEAK_GBS = 8000.0                                                                            # MI355X_MICROARCH.md
 RASTER_NAMES = {0: 'pillow-9.0.x (inferred, no fixture)', 1: 'pillow-12.2 (goldens)', 2: "recordings' Pillow (default; pinned by the reference's GIF frames)"}
 # committed PMC summaries (tools/pmc_summary.py) per workload: HBM traffic and VALU figures are PROFILE-DERIVED (measured with
 # rocprofv3 --pmc on the same command on an earlier box, not in this run) and labelled so in the JSON line
-PMC_PROFILES = {('Bounce', 100000): 'profiles/r03_bounce100k_pmc.json', ('Dropbox', 100000): 'profiles/r03_dropbox100k_pmc.json',
-                ('Urchin', 50000): 'profiles/r03_urchin50k_pmc.json', ('LuxoBall', 50000): 'profiles/r03_luxoball50k_pmc.json',
-                ('Object2', 200000): 'profiles/r03_object2_200k_pmc.json'}
-PMC_FALLBACK = {('Bounce', 100000): 'profiles/r02b_bounce100k_pmc.json', ('Dropbox', 100000): 'profiles/r02b_dropbox100k_pmc.json',
-                ('Urchin', 50000): 'profiles/r02b_urchin50k_pmc.json', ('LuxoBall', 50000): 'profiles/r02b_luxoball50k_pmc.json'}
+PMC_PROFILES = {('Bounce', 100000): 'profiles/r04_bounce100k_pmc.json', ('Dropbox', 100000): 'profiles/r04_dropbox100k_pmc.json',
+                ('Urchin', 50000): 'profiles/r04_urchin50k_pmc.json', ('LuxoBall', 50000): 'profiles/r04_luxoball50k_pmc.json',
+                ('Object2', 200000): 'profiles/r04_object2_200k_pmc.json', ('Crab', 20000): 'profiles/r04_crab20k_pmc.json'}
 
 
-def pmc_blocks(env_name, n_envs, dispatches_per_chunk=1):
-  """(traffic bytes per launch or None, traffic source, valu block or None) from the committed PMC summary of this workload."""
-  for table in (PMC_PROFILES, PMC_FALLBACK):
+FETCH_FACTOR = 2.0   # MI355X_MICROARCH.md "HBM": gfx950 FETCH_SIZE tallies 128-B requests at 64 B - exactly half the bytes of wide coalesced reads
+
+
+def pmc_blocks(env_name, n_envs, dispatches_per_chunk=1, steps_per_launch=None):
+  """(traffic bytes per launch or None, traffic detail dict, valu block or None) from the committed PMC summary of this workload.
+  The summary must carry the revision stamp of the device code this process runs (tools/csrc_rev.py) - a kernel change that
+  was not re-profiled yields None, not stale counters - and, where launches of several lengths were profiled together (jointed
+  classes: 50-step launches in the first rollout, 200-step launches after it), the group that matches `steps_per_launch`."""
+  from tools.csrc_rev import csrc_rev
+  for table in (PMC_PROFILES,):
     path = table.get((env_name, n_envs))
     if not path or not os.path.exists(os.path.join(ROOT, path)):
       continue
     try:
       prof = json.load(open(os.path.join(ROOT, path)))
+      meta = prof.get('_meta', {})
+      if meta.get('csrc_rev') != csrc_rev():
+        return None, {'source': path, 'dropped': f"profile taken on device code {meta.get('csrc_rev')}, this run is {csrc_rev()}: re-profile (tools/profile_all.sh)"}, None
       k = [x for x in prof if 'step_kernel' in x][0]
       c = prof[k]
-      traffic = src = None
+      groups = c.get('by_env_steps')
+      basis = 'all step_kernel dispatches of the profile'
+      if groups and steps_per_launch is not None:
+        g = str(int(round(steps_per_launch)))
+        if g not in groups:
+          return None, {'source': path, 'dropped': f'no profiled launches of {g} env-steps (profile has {sorted(groups)})'}, None
+        c, basis = groups[g], f'the profile\'s {g}-env-step launches only'
+      traffic = detail = None
       if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
-        traffic = (c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0 * dispatches_per_chunk
-        src = (f'{path}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (KB -> B) per step_kernel dispatch x {dispatches_per_chunk} dispatch(es) per '
-               'chunk of the batch; profile-derived, not measured in this run')
+        f, w = c['FETCH_SIZE']['mean'] * 1024.0 * dispatches_per_chunk, c['WRITE_SIZE']['mean'] * 1024.0 * dispatches_per_chunk
+        traffic = f + w
+        detail = {'source': path, 'basis': basis, 'dispatches_per_chunk': dispatches_per_chunk, 'fetch_raw': f, 'write': w,
+                  'traffic_fetch_corrected': FETCH_FACTOR * f + w,
+                  'note': 'rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes; KB -> B) per step_kernel dispatch; profile-derived, not measured in '
+                          'this run.  `traffic` = raw counters; traffic_fetch_corrected doubles FETCH_SIZE as the guide prescribes for wide coalesced '
+                          'reads on gfx950 (upper bound here: this path mixes 4 B/lane state loads with 16 B/lane scratch reloads)'}
       valu = None
       if 'SQ_WAVE_CYCLES' in c and 'SQ_ACTIVE_INST_VALU' in c:
         w = c['SQ_WAVE_CYCLES']['mean']
@@ -62,11 +82,10 @@ def pmc_blocks(env_name, n_envs, dispatches_per_chunk=1):
                 'waiting_frac_of_wave_cycles': c['SQ_WAIT_ANY']['mean'] / w if 'SQ_WAIT_ANY' in c else None,
                 'lanes_per_valu_inst': (c['SQ_THREAD_CYCLES_VALU']['mean'] / c['SQ_ACTIVE_INST_VALU']['mean']) if 'SQ_THREAD_CYCLES_VALU' in c else None,
                 'waves_per_dispatch': c['SQ_WAVES']['mean'] if 'SQ_WAVES' in c else None,
-                'waves_per_simd_limit': 2 if '<1, 0, 4, 1,' in k else 1,   # register-bound: only the circles-only one-body kernel fits twice (212 VGPRs)
-                'source': f'{path} (rocprofv3 --pmc SQ_* pass of the same command; profile-derived)'}
-      return traffic, src, valu
-    except Exception:
-      continue
+                'source': f'{path} ({basis}; rocprofv3 --pmc SQ_* pass of the same command; profile-derived)'}
+      return traffic, detail, valu
+    except Exception as ex:
+      return None, {'source': path, 'dropped': f'unreadable summary: {ex}'}, None
   return None, None, None
 
 
@@ -110,12 +129,12 @@ def parity_sample(desc, poses, sel, acts, T, gpu_state, gpu_lcd, idx, cores):
 class Workload:
   """One env class x batch size on one GPU: resident inputs, output tensors, and the rollout loop."""
 
-  def __init__(self, env_name, N, T, local, dev, seed, chunk=20):
+  def __init__(self, env_name, N, T, local, dev, seed, chunk=20, env_id_base=0):
     import torch
     import boxlcd_amd as B
     from boxlcd_amd._lib import Handle
     self.name, self.N, self.T, self.chunk = env_name, N, T, chunk
-    self.venv = B.BatchedWorldEnv(env_name, N, seed=seed)
+    self.venv = B.BatchedWorldEnv(env_name, N, seed=seed, env_id_base=env_id_base)
     self.d = d = self.venv.scene.desc
     self.h = Handle(d, N, local)
     self.poses_np, self.sel_np = self.venv.sample_initial(N)
@@ -164,11 +183,13 @@ class Workload:
     bpe = ALG_BYTES.get(self.name, 0)
     achieved = bpe * self.N * steps_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     cohorts = self.d.n_joints == 0 and self.N > 65536 and os.environ.get('BLCD_COHORTS', '2') != '1'
-    traffic, tsrc, valu = pmc_blocks(self.name, self.N, 2 if cohorts and os.environ.get('BLCD_COHORTS', '2') == '2' else 1)
-    if any(k.startswith('BLCD_') for k in os.environ) or self.T != 200:
-      traffic = tsrc = valu = None                     # the committed profiles describe the default knobs only
+    traffic, tsrc, valu = pmc_blocks(self.name, self.N, 2 if cohorts and os.environ.get('BLCD_COHORTS', '2') == '2' else 1, steps_per_launch)
+    if any(k.startswith('BLCD_') and k != 'BLCD_LAUNCH_LOG' for k in os.environ) or self.T != 200:
+      traffic = valu = None                            # the committed profiles describe the default knobs only
+      tsrc = {'dropped': 'BLCD_* overrides or a non-default rollout length: the committed profiles do not describe this run'}
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': traffic, 'traffic_source': tsrc, 'valu': valu, 'kernel': 'step_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
+            'traffic': traffic, 'traffic_detail': tsrc,
+            'traffic_over_algorithmic': (traffic / (bpe * self.N * steps_per_launch)) if traffic and bpe else None, 'valu': valu, 'kernel': 'step_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
             'env_steps_per_env_per_launch': steps_per_launch, 'alg_bytes_per_env_step': bpe,
             'note': 'path is VALU/latency-bound (SURVEY.md §8d): HBM fraction is reported as required, not the limiter'
                     + ('; this batch is stepped as two cohorts on two streams: a "launch" here is one chunk of the WHOLE batch (two '
@@ -177,6 +198,49 @@ class Workload:
 
   def close(self):
     self.h.close()
+
+
+def step_loop(env_name, N, local, steps, warmup=5):
+  """The call shape of the reference's policy-in-the-loop consumers (research/rl/ppo.py:127-133 `o, r, d, _ = env.step(a)`,
+  rl/sac.py:200-214): ONE env-step per call through BatchedWorldEnv.step_torch - device-resident actions in, observation dict
+  (full_state, proprio, lcd) of CUDA tensors out, nothing crosses PCIe.  The 'policy' is a fresh U(-1,1) action tensor per step
+  (torch.rand on the device, inside the timed loop, as a policy's forward pass would be)."""
+  import torch
+  import boxlcd_amd as B
+  env = B.BatchedWorldEnv(env_name, N, device=local, seed=4242)
+  env.reset_torch()
+  dev = torch.device('cuda', local)
+  a = torch.empty((N, env.act_size), dtype=torch.float32, device=dev)
+  for _ in range(warmup):
+    env.step_torch(a.uniform_(-1, 1))
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    obs, rew, done, _ = env.step_torch(a.uniform_(-1, 1))
+  torch.cuda.synchronize()
+  sec = time.perf_counter() - t0
+  env.close()
+  return {'value': steps * N / sec, 'unit': 'env-steps/s', 'env_steps_per_call': 1, 'calls': steps, 'ms_per_call': sec / steps * 1e3,
+          'note': 'BatchedWorldEnv.step_torch: blcd_step (one launch, one env-step) + blcd_get_obs (obs + LCD raster launch), device tensors in and out'}
+
+
+def wire_model(world, N, T, d, mode, step_s_per_rollout):
+  """Bytes a rollout puts on xGMI and what that predicts, so that the first real SCALE run can be checked against a number:
+  LCD frames travel at 1 bit per pixel, observations as float32.  xGMI is point-to-point, 7 links x ~153 GB/s per GPU
+  (MI355X_MICROARCH.md): a DIRECT all-gather uses all 7 links at once (each peer's shard arrives over its own link); a single
+  RING all-gather moves (world-1) shards over one link.  Gather overlaps the next rollout's stepping, so the predicted
+  weak-scaling efficiency is stepping time / max(stepping time, gather time)."""
+  LINK = 153e9
+  per_rank = N * T * (d.lcd_h * d.lcd_w // 8 + 4 * d.n_obs)
+  recv = (world - 1) * per_rank if mode == 'all' else 0
+  t_direct = per_rank / LINK
+  t_ring = (world - 1) * per_rank / LINK
+  eff = lambda tg: step_s_per_rollout / max(step_s_per_rollout, tg) if step_s_per_rollout > 0 else None
+  return {'bytes_sent_per_rank_per_rollout': per_rank, 'bytes_received_per_rank_per_rollout': recv if mode == 'all' else '(world-1) x per_rank on rank 0 only',
+          'link_GBps': LINK / 1e9, 'gather_s_direct_all_links': t_direct, 'gather_s_single_ring': t_ring, 'stepping_s_per_rollout_measured': step_s_per_rollout,
+          'predicted_efficiency_direct': eff(t_direct), 'predicted_efficiency_single_ring': eff(t_ring),
+          'predicted_at_8_ranks': {'gather_s_direct': per_rank / LINK, 'gather_s_single_ring': 7 * per_rank / LINK,
+                                   'efficiency_direct': eff(per_rank / LINK), 'efficiency_single_ring': eff(7 * per_rank / LINK)}}
 
 
 def time_rollouts(w, rollouts, warmup, bdist, torch, gather=True):
@@ -239,7 +303,9 @@ def main():
   N, T = args.envs, args.rollout_len
   overrides = {k: v for k, v in os.environ.items() if k.startswith('BLCD_') or k.startswith('BOXLCD_')}
 
-  w = Workload(args.env, N, T, local, dev, seed=1000 + rank)
+  # every rank: the SAME seed; the reset sampler keys its counter with the global env id (BatchedWorldEnv env_id_base), the
+  # mirror used here samples environments rank*N .. rank*N+N-1 of one world*N batch
+  w = Workload(args.env, N, T, local, dev, seed=1000, env_id_base=rank * N)
   d = w.d
   if world > 1:
     w.enable_gather(world, args.gather, rank)
@@ -271,6 +337,7 @@ def main():
     }
     if stepping_only is not None:
       out['stepping_only'] = stepping_only
+      out['wire'] = wire_model(world, N, T, d, args.gather, T * N * world / stepping_only['value'])
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args.env, T)
       idx = np.random.RandomState(0).choice(N, min(N, 1024), replace=False)
@@ -279,11 +346,34 @@ def main():
   w.close()
   del w
   torch.cuda.empty_cache()
+  if world > 1 and not args.no_configs and args.env == 'Bounce':
+    # BASELINE configs[3] and [4] AS STATED: the 50 000-env LuxoBall batch and the 200 000-env Object2 batch cut into `world`
+    # contiguous shards (strong scaling of a fixed batch), each rank stepping its shard and the finished rollout gathered over
+    # RCCL; every rank takes part (collectives), rank 0 reports.  `value` = whole-batch env-steps/s with the gather, max over ranks.
+    cfgs = {}
+    for name, n_total, rolls in (('LuxoBall', 50000, 2), ('Object2', 200000, 3)):
+      n_r = n_total // world                       # equal shards (all_gather_into_tensor); the remainder of an uneven cut is dropped and reported
+      ww = Workload(name, n_r, T, local, dev, seed=1000, env_id_base=rank * n_r)
+      ww.enable_gather(world, args.gather, rank)
+      sec = time_rollouts(ww, rolls, 1, bdist, torch)
+      sec2 = time_rollouts(ww, rolls, 0, bdist, torch, gather=False)
+      if rank == 0:
+        cfgs[f'{name}-{n_total}-sharded-x{world}'] = {
+            'value': rolls * T * n_r * world / sec, 'unit': 'env-steps/s', 'scaling': 'strong', 'envs_total': n_r * world, 'envs_per_gpu': n_r, 'rollouts': rolls,
+            'seconds': sec, 'gather': args.gather, 'stepping_only': {'value': rolls * T * n_r * world / sec2, 'unit': 'env-steps/s', 'seconds': sec2},
+            'wire': wire_model(world, n_r, T, ww.d, args.gather, sec2 / rolls), 'faulted_envs': int((ww.h.faults() != 0).sum())}
+      ww.close()
+      del ww
+      torch.cuda.empty_cache()
+    if rank == 0:
+      out['configs'] = cfgs
   if rank == 0 and world == 1 and not args.no_configs and args.env == 'Bounce':
+    # policy-in-the-loop call shape (one env-step per call, device tensors): what PPO / SAC consumers see
+    out['step_loop'] = {'Bounce-100000': step_loop('Bounce', 100000, local, 200), 'Urchin-50000': step_loop('Urchin', 50000, local, 40)}
     # the other BASELINE workloads, driver-run on this one GPU: north_star's Dropbox-100k target, configs[2] Urchin-50k, and the
     # whole batches of configs[3] LuxoBall-50k and configs[4] Object2-200k (they fit one MI355X)
     cfgs = {}
-    for name, n_envs, rolls in (('Dropbox', 100000, 20), ('Urchin', 50000, 3), ('LuxoBall', 50000, 2), ('Object2', 200000, 2)):
+    for name, n_envs, rolls in (('Dropbox', 100000, 20), ('Urchin', 50000, 3), ('LuxoBall', 50000, 2), ('Object2', 200000, 2), ('Crab', 20000, 1)):
       ww = Workload(name, n_envs, T, local, dev, seed=1000)
       sec = time_rollouts(ww, rolls, 1, bdist, torch)
       cfgs[f'{name}-{n_envs}'] = {'value': rolls * T * n_envs / sec, 'unit': 'env-steps/s', 'rollouts': rolls, 'seconds': sec,

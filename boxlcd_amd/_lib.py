@@ -10,6 +10,7 @@ BODY_F, JOINT_F, PAIR_F = 12, 5, 18
 
 SYMBOLS = {
     'blcd_version': (C.c_int, []),
+    'blcd_build_features': (C.c_int, []),
     'blcd_last_error': (C.c_char_p, []),
     'blcd_device_count': (C.c_int, []),
     'blcd_create': (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -22,6 +23,8 @@ SYMBOLS = {
     'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_reset_sampled': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_int32]),
     'blcd_sample_reseed': (C.c_int, [C.c_void_p]),
+    'blcd_sample_set_base': (C.c_int, [C.c_void_p, C.c_uint64]),
+    'blcd_get_shape_sel': (C.c_int, [C.c_void_p, C.c_void_p]),
     'blcd_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_rollout_bits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_goal_set': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -51,6 +54,12 @@ SYMBOLS = {
 }
 
 _lib = None
+FEATURE_WAVETIMES, FEATURE_SCHED = 1, 2
+
+
+def features():
+  """bit mask of the optional parts compiled into the library (include/boxlcd.h BLCD_FEATURE_*)"""
+  return load().blcd_build_features()
 
 
 def load():
@@ -191,6 +200,16 @@ class Handle:
 
   def sample_reseed(self):
     _check(self.lib.blcd_sample_reseed(self._h))
+
+  def sample_set_base(self, env_id_base):
+    """global id of this handle's environment 0 (sharded batches: rank * envs per rank)"""
+    _check(self.lib.blcd_sample_set_base(self._h, C.c_uint64(int(env_id_base))))
+
+  def shape_sel(self, out=None):
+    """int32 [n, nb]: the shape every body currently has ('random' objects choose one per reset)"""
+    out = np.zeros((self.n, self.nb), np.int32) if out is None else out
+    _check(self.lib.blcd_get_shape_sel(self._h, _ptr(out)))
+    return out
 
   def rollout(self, actions, T, lcd_out=None, obs_out=None):
     if actions is not None and not hasattr(actions, 'data_ptr'):

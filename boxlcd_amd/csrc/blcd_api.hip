@@ -154,6 +154,14 @@ __global__ void poses_kernel(const DevScene* __restrict__ S, const float* __rest
   }
 }
 
+__global__ void shape_sel_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, const int* __restrict__ eid,
+                                 int* __restrict__ out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int env = eid[e];
+  for (int i = 0; i < S->nb; ++i) out[(size_t)env * S->nb + i] = __float_as_int(st[(size_t)(i * kBodyFields + 17) * N + e]);
+}
+
 __global__ void faults_kernel(const DevScene* __restrict__ S, const float* __restrict__ st, int N, const int* __restrict__ eid,
                               int* __restrict__ out) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,12 +242,16 @@ __device__ inline int work_class1(const DevScene* __restrict__ S, const float* _
 __device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode, int tEnd) {
   // suspended environments first and together, by what they are suspended at: the launch that resumes them then runs what they
   // owe in dense, homogeneous waves; environments that have finished the rollout (tEnd > 0) go last
+#ifdef BLCD_SCHED
   const size_t po = (size_t)schedWordOffset(S->nb, S->nj, S->np);
   const uint32_t prog0 = __float_as_uint(st[po * N + slot]), prog1 = __float_as_uint(st[(po + 1) * N + slot]);
   if ((prog0 >> 18) & 1u) return 0;
   if ((prog1 >> 7) & 0x7fu) return 1;
   if (prog1 & 0x7fu) return 2;
   if (tEnd > 0 && (int)(prog0 & 0xffffu) >= tEnd) return kBins - 1;
+#else
+  (void)tEnd;
+#endif
   if (mode < 0) return 3;       // batches that are not sorted by work class: only the suspended ones move (stable sort)
   return 3 + work_class1(S, st, N, slot, mode);
 }
@@ -621,6 +633,8 @@ struct blcd_handle_s {
   int* dFaultAny = nullptr;  // device flag raised by step_kernel when an environment is faulted
   unsigned long long* dSchedStats = nullptr;   // blcd_sched_stats
   int* dEpisode = nullptr;                     // blcd_reset_sampled: per-environment reset count; staging of the sampled poses / shapes
+  uint64_t envIdBase = 0;                      // blcd_sample_set_base: global id of this handle's environment 0
+  std::vector<uint8_t> seen;                   // duplicate check of host index lists
   blcd_sample_op* dSampleOps = nullptr;
   float* dSamplePoses = nullptr;
   int* dSampleSel = nullptr;
@@ -690,6 +704,8 @@ static int out_done(blcd_handle h, int k, void* p, size_t bytes, void* dev) {
   return BLCD_OK;
 }
 
+static FILE* g_launchLog = nullptr;   // diagnostic: see launch_step
+
 // ---- template dispatch over (max bodies, max joints, max pair slots) -------------------------------------
 struct Cfg {
   int nb, nj, np, sh;
@@ -754,6 +770,10 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   BLCD_CONFIGS(X)
 #undef X
   HIPCHK(hipGetLastError());
+  if (g_launchLog) {   // BLCD_LAUNCH_LOG=<file>: one line per step_kernel dispatch, in dispatch order (tools/pmc_summary.py groups counters by launch shape)
+    fprintf(g_launchLog, "%d %d %d %d %d\n", nEnvSteps, nWorldSteps, n, cohort, (int)grid.x);
+    fflush(g_launchLog);
+  }
   if (cohort < 0 && pass + 1 == nPasses && stepBudget == 0) {
     HIPCHK(hipEventRecord(e1, stream));
     h->lastLaunches += 1;
@@ -918,6 +938,16 @@ __global__ void goal_eval_kernel(const blcd_goal_desc* __restrict__ G, int N, in
 extern "C" {
 
 int blcd_version(void) { return BLCD_VERSION; }
+int blcd_build_features(void) {
+  int f = 0;
+#ifdef BLCD_WAVETIMES
+  f |= BLCD_FEATURE_WAVETIMES;
+#endif
+#ifdef BLCD_SCHED
+  f |= BLCD_FEATURE_SCHED;
+#endif
+  return f;
+}
 const char* blcd_last_error(void) { return g_err.c_str(); }
 int blcd_device_count(void) {
   int n = 0;
@@ -958,9 +988,18 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   // the per-wave timers are compiled out of the product kernels (they cost every class ~20 registers): diagnostic builds only
   if (getenv("BLCD_WAVETIMES")) return fail(BLCD_ERR_UNSUPPORTED, "BLCD_WAVETIMES needs a library built with BLCD_DEFS=-DBLCD_WAVETIMES");
 #endif
+#ifndef BLCD_SCHED
+  // the environment-level schedulers are compiled out of the default build
+  for (const char* knob : {"BLCD_ASYNC", "BLCD_WAVE_BATCH", "BLCD_YIELD_PASSES"})
+    if (const char* ev = getenv(knob))
+      if (atoi(ev) > (knob[5] == 'Y' ? 1 : 0))
+        return fail(BLCD_ERR_UNSUPPORTED, "BLCD_ASYNC / BLCD_WAVE_BATCH / BLCD_YIELD_PASSES need a library built with BLCD_DEFS=-DBLCD_SCHED");
+#endif
   int ndev = blcd_device_count();
   if (ndev <= 0) return fail(BLCD_ERR_NO_DEVICE, "no HIP device available (boxlcd_hip has no CPU path)");
   if (device < 0 || device >= ndev) return fail(BLCD_ERR_NO_DEVICE, "device index out of range");
+  if (!g_launchLog)
+    if (const char* path = getenv("BLCD_LAUNCH_LOG")) g_launchLog = fopen(path, "a");
   blcd_handle h = new blcd_handle_s();
   int rc = lower_scene(*scene, &h->hostScene);
   if (rc) {
@@ -1051,6 +1090,7 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   // 5 / 10 / 15 / 20 - its waves are so uneven (5 of 64 lanes busy on average) that regrouping them twice as often pays; the circles
   // two-body class and the three-body class show no trend (Bounce2-100k, Object3-100k within noise or best at 20) and keep 20.
   if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 2 && kCfgs[h->cfg].sh == 0) h->rolloutChunk = 10;
+#ifdef BLCD_SCHED
   if (h->hostScene.nb <= 7) {
     if (const char* ev = getenv("BLCD_ASYNC")) h->asyncBudget = atoi(ev) > 0 ? atoi(ev) : 0;
     if (h->asyncBudget > 0) {
@@ -1085,6 +1125,7 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     }
     if (h->yieldPasses == 1 || h->yieldMaxLanes == 0) h->yieldPasses = 1, h->yieldMaxLanes = 0;
   }
+#endif
   for (int c = 1; c <= blcd_handle_s::kMaxCohorts; ++c) h->cohortLo[c] = n_envs;
   {
     int k = h->rebinEvery > 0 && !h->waveTimes && h->asyncBudget == 0 ? 2 : 1;     // the re-binned (oversubscribed, joint-free) batches
@@ -1159,10 +1200,25 @@ int blcd_pair_table(blcd_handle h, int32_t* pairs) {
   return BLCD_OK;
 }
 
+// An index list that names an environment twice would have two threads rebuild the same world (and, in the sampler, bump its
+// reset count twice): host lists are checked here; device lists are the caller's responsibility.
+static int check_idxs(blcd_handle h, const int32_t* idxs, int n, const char* who) {
+  if (!idxs || is_device_ptr(idxs)) return BLCD_OK;
+  h->seen.assign((size_t)h->N, 0);
+  for (int k = 0; k < n; ++k) {
+    const int e = idxs[k];
+    if (e < 0 || e >= h->N) return fail(BLCD_ERR_INVALID, std::string(who) + ": environment index out of range");
+    if (h->seen[e]) return fail(BLCD_ERR_INVALID, std::string(who) + ": an environment index appears twice");
+    h->seen[e] = 1;
+  }
+  return BLCD_OK;
+}
+
 int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const int32_t* shape_sel) {
   if (!h || !poses || n < 1) return fail(BLCD_ERR_INVALID, "blcd_reset: bad arguments");
   if (!idxs && n != h->N) return fail(BLCD_ERR_INVALID, "blcd_reset: idxs == NULL requires n == n_envs");
   HIPCHK(hipSetDevice(h->device));
+  if (int rcI = check_idxs(h, idxs, n, "blcd_reset")) return rcI;
   const int nb = h->hostScene.nb;
   const void *dIdx, *dPoses, *dSel;
   int rc;
@@ -1196,7 +1252,8 @@ __device__ inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint
 }
 constexpr int kMaxSampleOps = 160;
 __global__ void sample_kernel(const DevScene* __restrict__ S, const blcd_sample_op* __restrict__ ops, int nOps, const int* __restrict__ idxs, int n,
-                              int N, uint32_t k0, uint32_t k1, int* __restrict__ episode, float* __restrict__ poses, int* __restrict__ sel) {
+                              int N, uint32_t k0, uint32_t k1, unsigned long long idBase, int* __restrict__ episode, float* __restrict__ poses,
+                              int* __restrict__ sel) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int e = idxs ? idxs[k] : k;
@@ -1204,6 +1261,7 @@ __global__ void sample_kernel(const DevScene* __restrict__ S, const blcd_sample_
   const int nb = S->nb;
   const uint32_t epi = (uint32_t)episode[e];
   episode[e] = (int)(epi + 1u);
+  const unsigned long long gid = idBase + (unsigned long long)e;   // the environment's id in the whole (possibly sharded) batch
   double r[16];
   float px[20], py[20];      // b2Vec2 position of every body placed so far (float32, as behind the SWIG boundary)
   double ang[20];            // its angle as the reference holds it (float64)
@@ -1212,7 +1270,7 @@ __global__ void sample_kernel(const DevScene* __restrict__ S, const blcd_sample_
   uint32_t var = 0;
   auto uniform01 = [&]() {
     uint32_t x0, x1;
-    philox4x32_10(k0, k1, (uint32_t)e, epi, var++, 0u, &x0, &x1);
+    philox4x32_10(k0, k1, (uint32_t)gid, epi, var++, (uint32_t)(gid >> 32), &x0, &x1);
     return ((double)(x0 >> 5) * 67108864.0 + (double)(x1 >> 6)) * (1.0 / 9007199254740992.0);
   };
   for (int q = 0; q < nOps; ++q) {
@@ -1250,6 +1308,23 @@ __global__ void sample_kernel(const DevScene* __restrict__ S, const blcd_sample_
   }
 }
 
+static int sampler_buffers(blcd_handle h) {
+  if (h->dEpisode) return BLCD_OK;
+  const int nb = h->hostScene.nb;
+  HIPCHK(hipMalloc((void**)&h->dEpisode, (size_t)h->N * sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->dEpisode, 0, (size_t)h->N * sizeof(int), h->stream));
+  HIPCHK(hipMalloc((void**)&h->dSampleOps, kMaxSampleOps * sizeof(blcd_sample_op)));
+  HIPCHK(hipMalloc((void**)&h->dSamplePoses, (size_t)h->N * nb * 3 * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->dSampleSel, (size_t)h->N * nb * sizeof(int)));
+  return BLCD_OK;
+}
+
+int blcd_sample_set_base(blcd_handle h, uint64_t env_id_base) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_sample_set_base: bad handle");
+  h->envIdBase = env_id_base;
+  return BLCD_OK;
+}
+
 int blcd_sample_reseed(blcd_handle h) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_sample_reseed: bad handle");
   HIPCHK(hipSetDevice(h->device));
@@ -1269,19 +1344,14 @@ int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t s
       return fail(BLCD_ERR_INVALID, "blcd_reset_sampled: malformed sampling program");
   }
   HIPCHK(hipSetDevice(h->device));
-  if (!h->dEpisode) {
-    HIPCHK(hipMalloc((void**)&h->dEpisode, (size_t)h->N * sizeof(int)));
-    HIPCHK(hipMemsetAsync(h->dEpisode, 0, (size_t)h->N * sizeof(int), h->stream));
-    HIPCHK(hipMalloc((void**)&h->dSampleOps, kMaxSampleOps * sizeof(blcd_sample_op)));
-    HIPCHK(hipMalloc((void**)&h->dSamplePoses, (size_t)h->N * nb * 3 * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&h->dSampleSel, (size_t)h->N * nb * sizeof(int)));
-  }
-  const void* dIdx;
   int rc;
+  if ((rc = check_idxs(h, idxs, n, "blcd_reset_sampled"))) return rc;
+  if ((rc = sampler_buffers(h))) return rc;
+  const void* dIdx;
   if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
   HIPCHK(hipMemcpyAsync(h->dSampleOps, ops, (size_t)n_ops * sizeof(blcd_sample_op), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(sample_kernel, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->dScene, h->dSampleOps, n_ops, (const int*)dIdx, n, h->N,
-                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), h->dEpisode, h->dSamplePoses, h->dSampleSel);
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (unsigned long long)h->envIdBase, h->dEpisode, h->dSamplePoses, h->dSampleSel);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(reset_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, h->slotOf, (const int*)dIdx, n,
                      (const float*)h->dSamplePoses, (const int*)h->dSampleSel);
@@ -1296,6 +1366,7 @@ int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* p
   if (!h || !poses || n < 1) return fail(BLCD_ERR_INVALID, "blcd_set_poses: bad arguments");
   if (!idxs && n != h->N) return fail(BLCD_ERR_INVALID, "blcd_set_poses: idxs == NULL requires n == n_envs");
   HIPCHK(hipSetDevice(h->device));
+  if (int rcI = check_idxs(h, idxs, n, "blcd_set_poses")) return rcI;
   const int nb = h->hostScene.nb;
   const void *dIdx, *dPoses, *dMask;
   int rc;
@@ -1380,7 +1451,12 @@ static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t*
         chunk = c < 20.0f ? 20 : (c > 200.0f ? 200 : (int)c);
       }
     }
-    if (h->asyncBudget > 0 && T <= 60000) {
+#ifdef BLCD_SCHED
+    // the scheduler's progress word keeps the env-step in 16 bits: longer chunks / rollouts would overflow into the sub-step bits
+    if ((h->asyncBudget > 0 || h->waveBatch > 0 || h->yieldPasses > 1) && (chunk > 60000 || (h->asyncBudget > 0 && T > 60000)))
+      return fail(BLCD_ERR_UNSUPPORTED, "blcd_rollout: the environment-level schedulers handle at most 60000 env-steps per chunk / asynchronous rollout");
+#endif
+    if (h->asyncBudget > 0) {
       // Asynchronous rollout: no chunk boundaries at all.  Launch after launch, every unfinished environment
       // advances by at most asyncBudget world steps from its own position; the slot sort after each launch puts the suspended
       // ones together.  The loop ends when the device counter of unfinished environments reads zero.
@@ -1704,43 +1780,65 @@ int blcd_get_poses(blcd_handle h, float* poses) {
   return out_done(h, 1, poses, bytes, d);
 }
 
+int blcd_get_shape_sel(blcd_handle h, int32_t* shape_sel) {
+  if (!h || !shape_sel) return fail(BLCD_ERR_INVALID, "blcd_get_shape_sel: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->N * h->hostScene.nb * sizeof(int32_t);
+  void* d;
+  int rc;
+  if ((rc = out_ptr(h, 1, shape_sel, bytes, &d))) return rc;
+  hipLaunchKernelGGL(shape_sel_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dScene, h->st, h->N, h->eid, (int*)d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return out_done(h, 1, shape_sel, bytes, d);
+}
+
+// snapshot = header | state in slot order | slot -> env id table | reset counts of the device sampler (per env id)
 struct StateHeader {
   uint32_t magic, version;
   int32_t n, nb, nj, np;
   uint64_t words;
+  uint64_t envIdBase;
 };
 int blcd_get_state(blcd_handle h, void* blob, size_t* size) {
   if (!h || !size) return fail(BLCD_ERR_INVALID, "blcd_get_state: bad arguments");
   const size_t stBytes = h->words * (size_t)h->N * sizeof(float), idBytes = (size_t)h->N * sizeof(int);
-  size_t need = sizeof(StateHeader) + stBytes + idBytes;  // header | state in slot order | slot -> env id table
+  size_t need = sizeof(StateHeader) + stBytes + 2 * idBytes;
   if (!blob) {
     *size = need;
     return BLCD_OK;
   }
   if (*size < need) return fail(BLCD_ERR_INVALID, "blcd_get_state: buffer too small");
   HIPCHK(hipSetDevice(h->device));
-  StateHeader hd = {0x44434c42u, BLCD_VERSION, h->N, h->hostScene.nb, h->hostScene.nj, h->hostScene.np, (uint64_t)h->words};
+  StateHeader hd = {0x44434c42u, BLCD_VERSION, h->N, h->hostScene.nb, h->hostScene.nj, h->hostScene.np, (uint64_t)h->words, h->envIdBase};
   std::memcpy(blob, &hd, sizeof(hd));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy((char*)blob + sizeof(hd), h->st, stBytes, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy((char*)blob + sizeof(hd) + stBytes, h->eid, idBytes, hipMemcpyDeviceToHost));
+  if (h->dEpisode) HIPCHK(hipMemcpy((char*)blob + sizeof(hd) + stBytes + idBytes, h->dEpisode, idBytes, hipMemcpyDeviceToHost));
+  else std::memset((char*)blob + sizeof(hd) + stBytes + idBytes, 0, idBytes);
   *size = need;
   return BLCD_OK;
 }
 int blcd_set_state(blcd_handle h, const void* blob, size_t size) {
   if (!h || !blob) return fail(BLCD_ERR_INVALID, "blcd_set_state: bad arguments");
   const size_t stBytes = h->words * (size_t)h->N * sizeof(float), idBytes = (size_t)h->N * sizeof(int);
-  size_t need = sizeof(StateHeader) + stBytes + idBytes;
-  if (size != need) return fail(BLCD_ERR_INVALID, "blcd_set_state: size mismatch");
+  size_t need = sizeof(StateHeader) + stBytes + 2 * idBytes;
+  if (size < sizeof(StateHeader)) return fail(BLCD_ERR_INVALID, "blcd_set_state: size mismatch");
   StateHeader hd;
   std::memcpy(&hd, blob, sizeof(hd));
-  if (hd.magic != 0x44434c42u || hd.n != h->N || hd.nb != h->hostScene.nb || hd.nj != h->hostScene.nj ||
-      hd.np != h->hostScene.np || hd.words != h->words)
-    return fail(BLCD_ERR_INVALID, "blcd_set_state: snapshot belongs to a different scene/batch");
+  if (hd.magic != 0x44434c42u) return fail(BLCD_ERR_INVALID, "blcd_set_state: not a boxlcd snapshot");
+  if (hd.version != BLCD_VERSION) return fail(BLCD_ERR_INVALID, "blcd_set_state: snapshot written by another library version");
+  if (size != need || hd.n != h->N || hd.nb != h->hostScene.nb || hd.nj != h->hostScene.nj || hd.np != h->hostScene.np || hd.words != h->words)
+    return fail(BLCD_ERR_INVALID, "blcd_set_state: snapshot belongs to a different scene/batch/build");
   HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = sampler_buffers(h))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(h->st, (const char*)blob + sizeof(hd), stBytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->eid, (const char*)blob + sizeof(hd) + stBytes, idBytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->dEpisode, (const char*)blob + sizeof(hd) + stBytes + idBytes, idBytes, hipMemcpyHostToDevice));
+  h->envIdBase = hd.envIdBase;
   hipLaunchKernelGGL(invert_kernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, h->N);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -388,7 +388,10 @@ __global__ void set_poses_kernel(const DevScene* __restrict__ S, float* __restri
 #define BLCD_NAME(p, a, b, c, d) BLCD_PASTE5(p, a, b, c, d)
 
 void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipStream_t stream, const StepArgs& A) {
-  // the scheduler's kernel exists for the classes it can act on (see Env::kCanYield) and runs only when asked for
+  // the scheduler's kernel exists for the classes it can act on (see Env::kCanYield), runs only when asked for, and is compiled
+  // only into BLCD_DEFS=-DBLCD_SCHED builds (blcd_create refuses the scheduler knobs otherwise): the three schedulers were
+  // measured 25-60 % slower than the plain rollout and doubled the device code of every class
+#ifdef BLCD_SCHED
   if constexpr (BLCD_NB <= 7) {
     if (A.sched) {
       hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, true>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
@@ -396,6 +399,7 @@ void BLCD_NAME(launch_step_, BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH)(dim3 grid, hipS
       return;
     }
   }
+#endif
   hipLaunchKernelGGL((step_kernel<BLCD_NB, BLCD_NJ, BLCD_NP, BLCD_SH, false>), grid, dim3(kBlock), 0, stream, A.S, A.st, A.N, A.nSlots, A.eid, A.actions,
                      A.nEnvSteps, A.nWorldSteps, A.setMotors, A.lanes, A.waveTimes, A.actStride, A.lcdOut, A.obsOut, A.faultAny, A.pass, A.yieldMaxLanes, A.schedStats, A.lcdBits, A.stepBudget, A.resumeBatch, A.heavyEnd, A.nSimds);
 }

@@ -102,7 +102,13 @@ struct DevScene {
 BLCD_HD static inline int schedWordOffset(int nb, int nj, int np) {
   return nb * kBodyFields + np * kPairFields + nj * kJointFields + kWorldFields + (np + 3) / 4;
 }
+#ifdef BLCD_SCHED
 BLCD_HD static inline int stateWords(int nb, int nj, int np) { return schedWordOffset(nb, nj, np) + 2 + 3 * nb; }
+#else
+// default build: the environment-level schedulers (built, bit-neutral, measured slower) are compiled out
+// (BLCD_DEFS=-DBLCD_SCHED brings them back) and no slot carries their words
+BLCD_HD static inline int stateWords(int nb, int nj, int np) { return schedWordOffset(nb, nj, np); }
+#endif
 // word 0: env-step reached (16 bits) | sub-step (2) << 16 | suspended at a TOI event << 18
 // word 1: seeds of the islands suspended in their velocity sweeps (7 bits) | in their position iterations << 7 | islanded bodies << 14
 constexpr uint32_t kProgPendingMask1 = 0x3fffu;

@@ -319,7 +319,7 @@ class BatchedWorldEnv(_EnvSpec):
   (research/wrappers/async_vector_env.py: reset(idxs, **kwargs) :131-189, step(actions) :191-242) — one kernel launch
   per step instead of one pipe round-trip per env."""
 
-  def __init__(self, env_cls, num_envs, G={}, device=0, seed=0, raster_variant=None):
+  def __init__(self, env_cls, num_envs, G={}, device=0, seed=0, raster_variant=None, env_id_base=0):
     if isinstance(env_cls, str):
       from . import envs as _envs
       env_cls = getattr(_envs, env_cls)
@@ -332,15 +332,18 @@ class BatchedWorldEnv(_EnvSpec):
     self.single_action_space = self.action_space
     self._device = device
     self._h = None
+    # Sharded batches: this object's environment i is environment env_id_base + i of the whole batch.  With the SAME seed on
+    # every rank and env_id_base = rank * num_envs, the gathered shards are the batch one object of world x num_envs
+    # environments would have sampled (tests/test_gpu_api.py::test_shards_with_one_seed_are_one_batch).
+    self.env_id_base = int(env_id_base)
     self.ep_t = np.zeros(self.num_envs, np.int64)
     self.seed(seed)
 
   def seed(self, seed=0):
     self._seed = int(seed) & 0xffffffffffffffff
-    self._episode = np.zeros(self.num_envs, np.int64)          # resets so far per environment (= the device's counters)
-    self._mirror_episode = np.zeros(self.num_envs, np.int64)   # the same for sample_initial(), the host-side mirror
-    self._sel = np.zeros((self.num_envs, len(self.scene.bodies)), np.int32)
-    self._act_rng = np.random.Generator(np.random.Philox(key=int(seed) + 1))
+    self._mirror_episode = np.zeros(self.num_envs, np.int64)   # reset counts of sample_initial(), the host-side mirror (the device keeps its own)
+    # action tapes of sample_actions(): one stream per shard (shards with one seed must not replay each other's actions)
+    self._act_rng = np.random.Generator(np.random.Philox(key=int(seed) + 1 if self.env_id_base == 0 else [int(seed) + 1, self.env_id_base]))
     if self._h is not None:
       self._h.sample_reseed()
     return [seed]
@@ -349,6 +352,7 @@ class BatchedWorldEnv(_EnvSpec):
     if self._h is None:
       from ._lib import Handle
       self._h = Handle(self.scene.desc, self.num_envs, self._device)
+      self._h.sample_set_base(self.env_id_base)
     return self._h
 
   def close(self):
@@ -365,10 +369,11 @@ class BatchedWorldEnv(_EnvSpec):
   def _philox_u01(seed, env_ids, episodes, var):
     """Philox4x32-10, key = seed (lo, hi), counter = (env id, reset count, var, 0) -> float64 in [0, 1) from 53 bits"""
     M = np.uint64(0xffffffff)
-    c0 = np.asarray(env_ids, np.uint64) & M
+    gid = np.asarray(env_ids, np.uint64)
+    c0 = gid & M
     c1 = np.asarray(episodes, np.uint64) & M
     c2 = np.full_like(c0, var)
-    c3 = np.zeros_like(c0)
+    c3 = gid >> np.uint64(32)
     k0, k1 = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
     for _ in range(10):
       p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
@@ -377,9 +382,9 @@ class BatchedWorldEnv(_EnvSpec):
     return ((c0 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (c1 >> np.uint64(6)).astype(np.float64)) * (1.0 / 9007199254740992.0)
 
   def mirror_poses(self, env_ids, episodes):
-    """(poses float32 [n, nb, 3], shape_sel int32 [n, nb]) the device sampler gives environment `env_ids[i]` at its
-    `episodes[i]`-th reset."""
-    env_ids, episodes = np.asarray(env_ids, np.int64), np.asarray(episodes, np.int64)
+    """(poses float32 [n, nb, 3], shape_sel int32 [n, nb]) the device sampler gives this object's environment `env_ids[i]` at
+    its `episodes[i]`-th reset."""
+    env_ids, episodes = np.asarray(env_ids, np.int64) + self.env_id_base, np.asarray(episodes, np.int64)
     var = [0]
 
     def u01():
@@ -449,13 +454,10 @@ class BatchedWorldEnv(_EnvSpec):
     return ops
 
   def _reset_on_device(self, ii):
-    """reset environments ii (int32 numpy) from the device sampler; the host only advances its copy of the reset counts and
-    recomputes the shape choices (needed by the RGB / any-size render calls)."""
+    """reset environments ii (int32 numpy) from the device sampler.  Reset counts and shape choices live on the device only
+    (the render calls read the shapes back with blcd_get_shape_sel; snapshots carry the counts)."""
     h = self._handle()
     h.reset_sampled(None if len(ii) == self.num_envs and (ii == np.arange(self.num_envs)).all() else ii, self._seed, self.sample_program())
-    if any(o.kind == 1 for o in self.sample_program()):
-      self._sel[ii] = self.mirror_poses(ii, self._episode[ii])[1]
-    self._episode[ii] += 1
     self.ep_t[ii] = 0
 
   def sample_actions(self, T=None):
@@ -561,7 +563,7 @@ class BatchedWorldEnv(_EnvSpec):
     h = self._handle()
     if lcd_mode == '1' and (width, height) == (dw, dh):
       return h.get_obs(None)[1].astype(bool)
-    img = h.render_poses_ex(h.get_poses()[:, :, :3], self._sel, int(width), int(height), lcd_mode)
+    img = h.render_poses_ex(h.get_poses()[:, :, :3], h.shape_sel(), int(width), int(height), lcd_mode)
     return img.astype(bool) if lcd_mode == '1' else img
 
   def render_states(self, full_state):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BLCD_VERSION 100 /* 0.1.0 */
+#define BLCD_VERSION 101 /* 0.1.1: state snapshots carry the reset sampler's counters; blcd_build_features, blcd_sample_set_base, blcd_get_shape_sel */
 
 #define BLCD_MAX_POLY_VERTS 8
 #define BLCD_MAX_BODIES 20
@@ -95,6 +95,12 @@ typedef struct blcd_handle_s* blcd_handle;
 
 /* library */
 int blcd_version(void);
+/* Optional parts compiled into this library (BLCD_DEFS at build time): bit 0 per-wave timers (blcd_debug_wave_times),
+ * bit 1 the environment-level schedulers of DESIGN.md 4.4 (BLCD_ASYNC / BLCD_WAVE_BATCH / BLCD_YIELD_PASSES, blcd_sched_stats).
+ * Neither is in the default build; blcd_create fails with BLCD_ERR_UNSUPPORTED when a knob asks for a part that is absent. */
+#define BLCD_FEATURE_WAVETIMES 1
+#define BLCD_FEATURE_SCHED 2
+int blcd_build_features(void);
 const char* blcd_last_error(void);
 int blcd_device_count(void);
 
@@ -135,6 +141,14 @@ typedef struct blcd_sample_op {
 } blcd_sample_op;
 int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t seed, const blcd_sample_op* ops, int32_t n_ops);
 int blcd_sample_reseed(blcd_handle h);   /* reset counts back to 0 (env.seed()) */
+/* Sharded batches: the Philox counter's env id is env_id_base + (index inside this handle), so rank r of a batch cut into
+ * contiguous shards of n environments passes r * n and - with the SAME seed on every rank - the gathered batch is the batch one
+ * handle of world x n environments would have sampled (research/wrappers/async_vector_env.py has one seed per env process
+ * instead).  Default 0. */
+int blcd_sample_set_base(blcd_handle h, uint64_t env_id_base);
+/* The shape each body currently has (Object(shape='random'): world_env.py:273-274 picks one per reset): int32
+ * [n_envs][n_bodies], host|device.  What blcd_render_poses_ex needs as shape_sel to draw the batch's current states. */
+int blcd_get_shape_sel(blcd_handle h, int32_t* shape_sel);
 
 /* Replaces the `body.position = ...; body.angle = ...` overwrite of reset(full_state=/proprio=) (world_env.py:319-380):
  * b2Body::SetTransform semantics (velocities untouched, broad-phase proxy refreshed).  mask host uint8 [n_bodies] or NULL. */
@@ -219,8 +233,10 @@ int blcd_unpack_bits(const uint8_t* src, uint8_t* dst, int64_t n_pixels, void* s
 /* Body poses for host-side consumers: float32 [n_envs][n_bodies][4] = transform.position.x, .y, body.angle, awake. */
 int blcd_get_poses(blcd_handle h, float* poses);
 
-/* Full snapshot (positions, velocities, impulses, contacts, sleep state) — the reference never checkpoints env state
- * (SURVEY.md §5); needed for mid-rollout parity tests and exact resume.  *size in/out (query with blob == NULL). */
+/* Full snapshot (positions, velocities, impulses, contacts, sleep state, and the reset sampler's per-environment reset counts
+ * + env-id base, so a resumed run draws the same reset stream) — the reference never checkpoints env state
+ * (SURVEY.md §5); needed for mid-rollout parity tests and exact resume.  *size in/out (query with blob == NULL).
+ * blcd_set_state refuses snapshots written by another BLCD_VERSION or another build's state layout. */
 int blcd_get_state(blcd_handle h, void* blob, size_t* size);
 int blcd_set_state(blcd_handle h, const void* blob, size_t size);
 

@@ -106,6 +106,9 @@ int32_t b2o_collide(const float* specA, const float* poseA, const float* specB, 
 double b2o_rollout(const b2o_scene_desc* scene, int32_t n, int32_t T, int32_t threads, const float* poses,
                    const int32_t* shape_sel, const float* actions, float* obs_out, uint8_t* lcd_out, float* state_out,
                    int32_t render_every_step);
+/* the same, keeping every env-step's observation and frame: obs_out [T][n][n_obs], lcd_out [T][n][h][w] */
+double b2o_rollout_frames(const b2o_scene_desc* scene, int32_t n, int32_t T, int32_t threads, const float* poses,
+                          const int32_t* shape_sel, const float* actions, float* obs_out, uint8_t* lcd_out, float* state_out);
 
 #ifdef __cplusplus
 }

@@ -507,4 +507,36 @@ double b2o_rollout(const b2o_scene_desc* scene, int32_t n, int32_t T, int32_t th
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// The same rollout, keeping what _get_obs / lcd_render return after EVERY env-step (world_env.py:458): obs_out float32
+// [T][n][n_obs], lcd_out uint8 [T][n][h][w] - the layout of the product's blcd_rollout outputs - plus the final state.
+double b2o_rollout_frames(const b2o_scene_desc* scene, int32_t n, int32_t T, int32_t threads, const float* poses,
+                          const int32_t* shape_sel, const float* actions, float* obs_out, uint8_t* lcd_out, float* state_out) {
+  const b2o_scene_desc& S = *scene;
+  if (threads < 1) threads = 1;
+  const size_t px = (size_t)S.lcd_w * S.lcd_h;
+  auto work = [&](int lo, int hi) {
+    std::vector<double> obs(S.n_obs > 0 ? S.n_obs : 1);
+    std::vector<float> zero(S.n_act > 0 ? S.n_act : 1, 0.0f);
+    for (int k = lo; k < hi; ++k) {
+      b2o_env* e = b2o_create(scene);
+      b2o_reset(e, poses + (size_t)k * S.n_bodies * 3, shape_sel ? shape_sel + (size_t)k * S.n_bodies : nullptr);
+      for (int t = 0; t < T; ++t) {
+        b2o_env_step(e, actions ? actions + ((size_t)t * n + k) * S.n_act : zero.data());
+        if (obs_out) {
+          b2o_get_obs(e, obs.data());
+          for (int i = 0; i < S.n_obs; ++i) obs_out[((size_t)t * n + k) * S.n_obs + i] = (float)obs[i];
+        }
+        if (lcd_out) b2o_render(e, lcd_out + ((size_t)t * n + k) * px);
+      }
+      if (state_out) b2o_dump(e, state_out + (size_t)k * S.n_bodies * B2O_BODY_STATE_FLOATS, nullptr, nullptr);
+      b2o_destroy(e);
+    }
+  };
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int i = 0; i < threads; ++i) th.emplace_back(work, (int)((int64_t)n * i / threads), (int)((int64_t)n * (i + 1) / threads));
+  for (auto& t : th) t.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 }  // extern "C"

@@ -27,6 +27,7 @@ def load():
     _lib = C.CDLL(LIB_PATH)
     _lib.b2o_create.restype = C.c_void_p
     _lib.b2o_rollout.restype = C.c_double
+    _lib.b2o_rollout_frames.restype = C.c_double
     _lib.b2o_num_pairs.restype = C.c_int32
     _lib.b2o_contact_order.restype = C.c_int32
     global _ellipse_rgb_lut
@@ -224,4 +225,18 @@ def rollout(desc, poses, shape_sel, actions, T, threads=1, want_obs=True, want_l
   st = np.zeros((n, desc.n_bodies, BODY_F), np.float32) if want_state else None
   sec = lib.b2o_rollout(C.byref(desc), n, int(T), int(threads), _p(poses), _p(sel), _p(act), _p(obs), _p(lcd), _p(st),
                         int(bool(render_every_step)))
+  return sec, obs, lcd, st
+
+
+def rollout_frames(desc, poses, shape_sel, actions, T, threads=1):
+  """Every env-step's outputs: (seconds, obs f32 [T,n,obs], lcd u8 [T,n,h,w], final state f32 [n,nb,12])."""
+  lib = load()
+  poses = np.ascontiguousarray(poses, np.float32)
+  n = poses.shape[0]
+  sel = None if shape_sel is None else np.ascontiguousarray(shape_sel, np.int32)
+  act = None if actions is None else np.ascontiguousarray(actions, np.float32)
+  obs = np.zeros((T, n, desc.n_obs), np.float32)
+  lcd = np.zeros((T, n, desc.lcd_h, desc.lcd_w), np.uint8)
+  st = np.zeros((n, desc.n_bodies, BODY_F), np.float32)
+  sec = lib.b2o_rollout_frames(C.byref(desc), n, int(T), int(threads), _p(poses), _p(sel), _p(act), _p(obs), _p(lcd), _p(st))
   return sec, obs, lcd, st

@@ -289,7 +289,7 @@ def test_device_reset_sampler_equals_its_host_mirror(name):
   env.reset()
   h = env._handle()
   p0, s0 = env.mirror_poses(np.arange(n), np.zeros(n, np.int64))
-  assert (h.get_poses()[:, :, :3] == p0).all() and (env._sel == s0).all()
+  assert (h.get_poses()[:, :, :3] == p0).all() and (h.shape_sel() == s0).all()
   env.reset()
   p1, s1 = env.mirror_poses(np.arange(n), np.ones(n, np.int64))
   assert (h.get_poses()[:, :, :3] == p1).all() and (p1 != p0).any()
@@ -305,10 +305,58 @@ def test_device_reset_sampler_equals_its_host_mirror(name):
     env.step(acts[t])
   st = h.debug_dump()[0]
   pm = p1.copy(); pm[idxs] = p2
-  sm = env._sel
+  sm = h.shape_sel()
   sub = np.array([0, 5, 77, 1500, 2999])
   _, _, _, ost = pyb2o.rollout(env.scene.desc, pm[sub], sm[sub], acts[:, sub], 5, threads=4)
   assert (ost == st[sub]).all()
+  env.close()
+
+
+@pytest.mark.parametrize('name', ['Object2', 'LuxoBall'])
+def test_shards_with_one_seed_are_one_batch(name):
+  """Sharded batches: every rank uses the SAME seed and env_id_base = rank * envs-per-rank; the device sampler keys
+  its Philox counter with the global env id, so the shards' starts - poses and 'random' shape choices - are exactly the starts
+  of one batch of world x n environments, at the first and at later resets, and a partial reset on one shard draws what the
+  whole batch would draw for those environments."""
+  n, world = 1000, 2
+  whole = B.BatchedWorldEnv(name, n * world, seed=77)
+  whole.reset()
+  whole.reset(np.array([3, n + 3], np.int32))
+  wp, ws = whole._handle().get_poses()[:, :, :3], whole._handle().shape_sel()
+  for r in range(world):
+    shard = B.BatchedWorldEnv(name, n, seed=77, env_id_base=r * n)
+    shard.reset()
+    shard.reset(np.array([3], np.int32))
+    h = shard._handle()
+    assert (h.get_poses()[:, :, :3] == wp[r * n:(r + 1) * n]).all() and (h.shape_sel() == ws[r * n:(r + 1) * n]).all()
+    pm, sm = shard.mirror_poses(np.arange(n), np.where(np.arange(n) == 3, 1, 0))      # the host mirror follows the base too
+    assert (pm == wp[r * n:(r + 1) * n]).all() and (sm == ws[r * n:(r + 1) * n]).all()
+    shard.close()
+  assert (wp[:n] != wp[n:]).any()
+  whole.close()
+
+
+def test_snapshot_carries_the_reset_counters_and_duplicate_indices_are_refused():
+  """blcd_get_state / blcd_set_state include the device sampler's per-environment reset counts (a resumed run draws the same
+  reset stream); an index list naming an environment twice is refused (two threads would rebuild one world)."""
+  env = B.BatchedWorldEnv('Object2', 512, seed=3)
+  env.reset()
+  env.reset(np.array([7, 9], np.int32))
+  h = env._handle()
+  blob = h.get_state()
+  env.reset()
+  after = (h.get_poses().copy(), h.shape_sel().copy())
+  env.reset()                       # moves the counters on
+  h.set_state(blob)
+  env.reset()                       # ... and from the restored snapshot the same draw comes again
+  assert (h.get_poses() == after[0]).all() and (h.shape_sel() == after[1]).all()
+  bad = blob.copy(); bad[4] ^= 1    # another library version
+  with pytest.raises(RuntimeError, match='version'):
+    h.set_state(bad)
+  for call in (lambda: env.reset(np.array([5, 6, 5], np.int32)), lambda: h.set_poses(np.array([1, 1], np.int32), np.zeros((2, 2, 3), np.float32)),
+               lambda: h.reset(np.array([2, 2], np.int32), np.zeros((2, 2, 3), np.float32))):
+    with pytest.raises(RuntimeError, match='twice'):
+      call()
   env.close()
 
 

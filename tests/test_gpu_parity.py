@@ -240,6 +240,32 @@ def test_full_size_baseline_batches(name, n, T):
   h.close()
 
 
+@pytest.mark.parametrize('name', sorted(B.env_map))
+def test_every_frame_of_a_fused_rollout_equals_the_oracle(name):
+  """The soak of tools/soak.py inside the suite: every env class of the catalogue, 256 environments, 200
+  env-steps with random actions through blcd_rollout - the FUSED path the bench times (chunked launches, frames and observation
+  rows written by step_kernel itself) - and EVERY one of the 200 x 256 LCD frames bit for bit, every observation row to 1e-6
+  (float64 sin/cos: ocml vs glibc) and the final body state bit for bit against the oracle stepped one env-step at a time."""
+  n, T = 256, 200
+  env = B.BatchedWorldEnv(name, n, seed=2024)
+  poses, sel = env.sample_initial(n)
+  acts = env.sample_actions(T)
+  d = env.scene.desc
+  h = Handle(d, n, 0)
+  h.reset(None, poses, sel)
+  lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
+  obs = np.zeros((T, n, d.n_obs), np.float32)
+  h.rollout(acts, T, lcd, obs)
+  state = h.debug_dump()[0]
+  assert not h.faults().any()
+  h.close()
+  _, oobs, olcd, ost = pyb2o.rollout_frames(d, poses, sel, acts, T, threads=16)
+  bad = np.argwhere(~(lcd == olcd).reshape(T, n, -1).all(2))
+  assert len(bad) == 0, f'{len(bad)} of {T * n} frames differ, first (t, env) = {bad[0]}'
+  assert np.abs(obs - oobs).max() < 1e-6
+  assert (state == ost).all()
+
+
 @pytest.mark.parametrize('name,n', [('UrchinBall', 100), ('Bounce', 1000), ('Object2', 77)])
 def test_fused_rollout_ragged_batch_matches_oracle(name, n):
   """blcd_rollout (fused chunks, re-binning between chunks, per-step LCD/obs rows) on batch sizes that are not multiples of the
@@ -351,12 +377,34 @@ def test_rebin_and_cohort_knobs_on_small_batches_change_nothing(monkeypatch, n):
       assert (x == y).all()
 
 
+def _needs_sched_build():
+  """the three environment-level schedulers are opt-in at build time (BLCD_DEFS=-DBLCD_SCHED; DESIGN.md 4.4: bit-neutral, slower)"""
+  from boxlcd_amd import _lib
+  if not _lib.features() & _lib.FEATURE_SCHED:
+    pytest.skip('library built without -DBLCD_SCHED (the default): the rejected schedulers are compiled out')
+
+
+def test_default_build_refuses_the_scheduler_knobs(monkeypatch):
+  from boxlcd_amd import _lib
+  if _lib.features() & _lib.FEATURE_SCHED:
+    pytest.skip('scheduler build')
+  env, poses, sel = parity.make_batch('Dropbox', 256, 1)
+  for k, v in (('BLCD_ASYNC', '3'), ('BLCD_WAVE_BATCH', '4'), ('BLCD_YIELD_PASSES', '2')):
+    monkeypatch.setenv(k, v)
+    with pytest.raises(RuntimeError, match='BLCD_SCHED'):
+      Handle(env.scene.desc, 256, 0)
+    monkeypatch.delenv(k)
+  monkeypatch.setenv('BLCD_YIELD_PASSES', '1')       # "off" is accepted
+  Handle(env.scene.desc, 256, 0).close()
+
+
 @pytest.mark.parametrize('name,n', [('Dropbox', 5000), ('Object2', 5000), ('Object3', 3000), ('Bounce2', 3000)])
 def test_suspending_straggler_environments_changes_nothing(monkeypatch, name, n):
   """Environment-level scheduling of fused chunks: a lane whose joint-free island has not converged after 24 velocity sweeps may
   suspend its environment; a later pass of the same chunk resumes it at that sweep.  Placement in time only: frames,
   observations and the full state equal the single-pass run, whatever the policy (never / at most 32 lanes / always / at most 8 lanes), and
   equal the oracle on a sample."""
+  _needs_sched_build()
   T = 60
   env, poses, sel = parity.make_batch(name, n, 21)
   d = env.scene.desc
@@ -389,6 +437,7 @@ def test_asynchronous_rollouts_change_nothing(monkeypatch, name, n):
   position; an environment suspends at velocity sweep 24 of a joint-free island, at position iteration 12 of a staged island or at
   its first TOI event when few lanes of its wave are in the same situation, and pays what it owes in a later launch, sorted next
   to its like.  Scheduling only: frames, observations and the full state equal the plain rollout and the oracle."""
+  _needs_sched_build()
   T = 40
   env, poses, sel = parity.make_batch(name, n, 33)
   acts = env.sample_actions(T)

@@ -120,7 +120,7 @@ def test_header_symbols_exported_by_library():
   for name in declared:
     assert hasattr(lib, name), name
   lib.blcd_version.restype = ctypes.c_int
-  assert lib.blcd_version() == 100
+  assert lib.blcd_version() == int(re.search(r"#define BLCD_VERSION (\d+)", hdr).group(1)) == 101
 
 
 def test_scene_struct_layout_matches_c_header():
@@ -202,9 +202,12 @@ def test_reset_stream_is_counter_based_and_sharding_invariant():
   # KAT through the public helper: counter (0,0,0,0), key 0 -> first two words 6627e8d5 e169c58d
   u = V._philox_u01(0, [0], [0], 0)[0]
   assert u == ((0x6627e8d5 >> 5) * 67108864.0 + (0xe169c58d >> 6)) / 9007199254740992.0
-  u = V._philox_u01(0xffffffffffffffff, [0xffffffff], [0xffffffff], 0xffffffff)
-  # (counter word 3 is fixed at 0 in the stream, so the all-ones KAT does not apply; determinism + range instead)
-  assert 0.0 <= u[0] < 1.0 and u[0] == V._philox_u01(0xffffffffffffffff, [0xffffffff], [0xffffffff], 0xffffffff)[0]
+  # counter word 3 = the high half of the (64-bit) global env id: the all-ones vector -> 408f276d 41c83b0e
+  u = V._philox_u01(0xffffffffffffffff, [0xffffffffffffffff], [0xffffffff], 0xffffffff)
+  assert u[0] == ((0x408f276d >> 5) * 67108864.0 + (0x41c83b0e >> 6)) / 9007199254740992.0
+  # counter (243f6a88 85a308d3 13198a2e 03707344), key (a4093822 299f31d0) -> d16cfe09 94fdcceb (the digits-of-pi vector)
+  u = V._philox_u01(0x299f31d0a4093822, [0x03707344243f6a88], [0x85a308d3], 0x13198a2e)
+  assert u[0] == ((0xd16cfe09 >> 5) * 67108864.0 + (0x94fdcceb >> 6)) / 9007199254740992.0
   for name in ('Urchin', 'LuxoBall', 'Object2', 'Crab'):
     a = V(name, 64, seed=9)
     b = V(name, 7, seed=9)
@@ -215,3 +218,7 @@ def test_reset_stream_is_counter_based_and_sharding_invariant():
     assert (pa2 != pa).any() and (a.mirror_poses([5], [1])[0] == pa2[5]).all()
     c = V(name, 64, seed=10)
     assert (c.sample_initial(64)[0] != pa).any()
+    # shards: same seed, env_id_base = first global id of the shard -> the shard IS that part of the batch
+    s1 = V(name, 32, seed=9, env_id_base=32)
+    p1, q1 = s1.sample_initial(32)
+    assert (p1 == pa[32:]).all() and (q1 == sa[32:]).all()
