@@ -375,7 +375,7 @@ def main():
     cfgs = {}
     for name, n_envs, rolls in (('Dropbox', 100000, 20), ('Urchin', 50000, 3), ('LuxoBall', 50000, 2), ('Object2', 200000, 2), ('Crab', 20000, 1)):
       ww = Workload(name, n_envs, T, local, dev, seed=1000)
-      sec = time_rollouts(ww, rolls, 1, bdist, torch)
+      sec = time_rollouts(ww, rolls, 0 if name == 'Crab' else 1, bdist, torch)     # the largest class: one cold rollout (seconds each)
       cfgs[f'{name}-{n_envs}'] = {'value': rolls * T * n_envs / sec, 'unit': 'env-steps/s', 'rollouts': rolls, 'seconds': sec,
                                   'faulted_envs': int((ww.h.faults() != 0).sum()), 'roofline': ww.roofline(rolls)}
       ww.close()

@@ -5,7 +5,8 @@ import numpy as np
 from .scene import SceneDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libboxlcd_hip.so')
+# BLCD_LIB: a side-by-side diagnostic build (__graft_entry__ BLCD_VARIANT); the product library otherwise
+LIB_PATH = os.path.join(_HERE, os.environ.get('BLCD_LIB', 'libboxlcd_hip.so'))
 BODY_F, JOINT_F, PAIR_F = 12, 5, 18
 
 SYMBOLS = {

@@ -298,72 +298,82 @@ __device__ inline int work_class1(const DevScene* __restrict__ S, const float* _
 
 // The three re-bin kernels sort ONE slot range (a cohort, or all slots): st / keys / eid point at the range's first slot, N stays
 // the stride between state fields, n is the number of slots in the range and lo its first slot (slotOf holds absolute slots).
-__global__ __launch_bounds__(kRebinBlock) void rebin_hist_kernel(const DevScene* __restrict__ S, const float* __restrict__ st,
-                                                                 int N, int n, uint8_t* __restrict__ keys, int* __restrict__ counts, int mode, int tEnd) {
+// Every workgroup of the three is ONE wave (kRebinBlock slots = kRebinBlock / 64 per lane).  A cohort's sort runs while the other
+// cohort's step_kernel holds the SIMDs with 512-register waves: a multi-wave workgroup then has to wait for a CU with room on
+// all its SIMDs at once - rocprofv3 showed the 256-thread histogram of a Dropbox-100k cohort taking 4.1 ms (572 us on average,
+// 11 % of the GPU time of a rollout) against 9 us on an idle GPU, and the cohort behind it idle meanwhile; a single wave fits
+// wherever one SIMD has a free slot (profiles/r04_dropbox100k_timeline_*.txt).
+__global__ __launch_bounds__(64) void rebin_hist_kernel(const DevScene* __restrict__ S, const float* __restrict__ st,
+                                                        int N, int n, uint8_t* __restrict__ keys, int* __restrict__ counts, int mode, int tEnd) {
   __shared__ int h[kBins];
+  static_assert(kBins <= 64, "one lane per bin");
   if (threadIdx.x < kBins) h[threadIdx.x] = 0;
   __syncthreads();
-  int slot = blockIdx.x * kRebinBlock + threadIdx.x;
-  if (slot < n) {
-    int k = work_class(S, st, N, slot, mode, tEnd);
-    keys[slot] = (uint8_t)k;
-    atomicAdd(&h[k], 1);
+#pragma unroll 1
+  for (int q = 0; q < kRebinBlock / 64; ++q) {
+    const int slot = blockIdx.x * kRebinBlock + q * 64 + threadIdx.x;
+    if (slot < n) {
+      const int k = work_class(S, st, N, slot, mode, tEnd);
+      keys[slot] = (uint8_t)k;
+      atomicAdd(&h[k], 1);
+    }
   }
   __syncthreads();
   if (threadIdx.x < kBins) counts[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];  // bin-major
 }
 
-// exclusive scan of counts[bin][block] in bin-major order (single block; nBlocks*kBins entries)
-__global__ void rebin_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int n) {
-  __shared__ int part[1024];
-  int tid = threadIdx.x, per = (n + 1023) / 1024;
-  int lo = tid * per, hi = lo + per < n ? lo + per : n;
+// exclusive scan of counts[bin][block] in bin-major order: one wave, lane l owns a contiguous run of entries
+__global__ __launch_bounds__(64) void rebin_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int n) {
+  const int lane = threadIdx.x, per = (n + 63) / 64;
+  const int lo = lane * per, hi = lo + per < n ? lo + per : n;
   int sum = 0;
   for (int i = lo; i < hi; ++i) sum += counts[i];
-  part[tid] = sum;
-  __syncthreads();
-  // exclusive scan of the 1024 partial sums (Hillis-Steele in LDS: 10 steps instead of a 1024-long serial loop)
-  for (int d = 1; d < 1024; d <<= 1) {
-    int v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
   }
-  int excl = part[tid] - sum;
-  __syncthreads();
-  part[tid] = excl;
-  __syncthreads();
-  int acc = part[tid];
+  int acc = incl - sum;
   for (int i = lo; i < hi; ++i) {
+    const int c = counts[i];
     offsets[i] = acc;
-    acc += counts[i];
+    acc += c;
   }
 }
 
 // stable scatter: new slot = offset[bin][block] + rank of this slot among same-bin slots of the block (in slot order)
-__global__ __launch_bounds__(kRebinBlock) void rebin_move_kernel(const float* __restrict__ st, float* __restrict__ st2, int N, int n, int lo,
-                                                                 int words, const uint8_t* __restrict__ keys,
-                                                                 const int* __restrict__ offsets, const int* __restrict__ eid,
-                                                                 int* __restrict__ eid2, int* __restrict__ slotOf) {
-  __shared__ int waveCount[kRebinBlock / 64][kBins];
-  int slot = blockIdx.x * kRebinBlock + threadIdx.x;
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int key = slot < n ? (int)keys[slot] : -1;
-  int rankInWave = 0;
-  for (int b = 0; b < kBins; ++b) {
-    unsigned long long m = __ballot(key == b);
-    if (key == b) rankInWave = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) waveCount[wv][b] = __popcll(m);
-  }
+__global__ __launch_bounds__(64) void rebin_move_kernel(const float* __restrict__ st, float* __restrict__ st2, int N, int n, int lo,
+                                                        int words, const uint8_t* __restrict__ keys,
+                                                        const int* __restrict__ offsets, const int* __restrict__ eid,
+                                                        int* __restrict__ eid2, int* __restrict__ slotOf) {
+  __shared__ int nextLds[kBins];   // where the block's next slot of each bin goes
+  volatile int* next = nextLds;    // lanes read what another lane of the wave wrote a round earlier
+  const int lane = threadIdx.x;
+  if (lane < kBins) next[lane] = offsets[lane * gridDim.x + blockIdx.x];
   __syncthreads();
-  if (slot >= n) return;
-  int base = offsets[key * gridDim.x + blockIdx.x];
-  for (int w2 = 0; w2 < wv; ++w2) base += waveCount[w2][key];
-  int dst = base + rankInWave;
-  for (int f = 0; f < words; ++f) st2[(size_t)f * N + dst] = st[(size_t)f * N + slot];
-  int e = eid[slot];
-  eid2[dst] = e;
-  slotOf[e] = lo + dst;
+#pragma unroll 1
+  for (int q = 0; q < kRebinBlock / 64; ++q) {
+    const int slot = blockIdx.x * kRebinBlock + q * 64 + lane;
+    const int key = slot < n ? (int)keys[slot] : -1;
+    int dst = -1;
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {   // one round per distinct key of these 64 slots (waves of a sorted batch hold one to three)
+      const int k = __shfl(key, __ffsll((long long)todo) - 1, 64);
+      const unsigned long long m = __ballot(key == k);
+      if (key == k) dst = next[k] + __popcll(m & ((1ull << lane) - 1ull));
+      __builtin_amdgcn_wave_barrier();            // every read of next[k] above is issued before the update below (one wave, in-order LDS)
+      if (lane == __ffsll((long long)m) - 1) next[k] += __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~m;
+    }
+    if (slot < n) {
+      for (int f = 0; f < words; ++f) st2[(size_t)f * N + dst] = st[(size_t)f * N + slot];
+      const int e = eid[slot];
+      eid2[dst] = e;
+      slotOf[e] = lo + dst;
+    }
+  }
 }
 
 __global__ void invert_kernel(const int* __restrict__ eid, int* __restrict__ slotOf, int n) {
@@ -614,6 +624,12 @@ struct blcd_handle_s {
   float estMsPerStep = 0.0f;  // step-kernel time per env step of the last fused rollout (sizes the chunks of jointed scenes)
   unsigned long long* waveTimes = nullptr;  // per-wave duration of the last step launch (diagnostic, BLCD_WAVETIMES=1)
   int stepsSinceRebin = 0;
+  // Re-binned batches right after a FULL reset: every environment is falling / landing / settling, every wave holds a lane that
+  // runs all its sweeps, so all waves of a chunk last about equally long and a batch of 1.5 x as many waves as SIMDs needs two
+  // rounds per chunk - unless the chunks are short enough for the two cohorts to interleave.  For the first
+  // phase0Steps env-steps after a full reset the chunks are phase0Chunk long (0 = no such phase).  BLCD_CHUNK0=<steps>:<len>.
+  int phase0Steps = 0, phase0Chunk = 0, phase0NoSort = 1;
+  long long stepsSinceFullReset = 1 << 30;
   // Cohorts: an oversubscribed joint-free batch is stepped as two slot ranges on two streams, each re-binned within itself, so
   // that neither waits at a chunk boundary for the slowest wave of the whole batch.  cohortLo[c] ..
   // cohortLo[c + 1] are cohort c's slots; cohort 0 runs on the handle's stream, cohort c > 0 on cstream[c].
@@ -705,6 +721,7 @@ static int out_done(blcd_handle h, int k, void* p, size_t bytes, void* dev) {
 }
 
 static FILE* g_launchLog = nullptr;   // diagnostic: see launch_step
+constexpr int kBigLanes = BLCD_BIG_LANES;   // blcd_world.h
 
 // ---- template dispatch over (max bodies, max joints, max pair slots) -------------------------------------
 struct Cfg {
@@ -806,10 +823,10 @@ static int launch_rebin(blcd_handle h, bool midChunk = false, int tEnd = 0) {
     int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
     int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
     h->sortedBlocks[c] = midChunk ? 0 : nBlocks;
-    hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->dScene, h->st + lo, h->N, n, h->keys + lo, counts,
+    hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(64), 0, stream, h->dScene, h->st + lo, h->N, n, h->keys + lo, counts,
                        midChunk && h->rebinEvery <= 0 ? -1 : h->binMode, tEnd);
-    hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, offsets, nBlocks * kBins);
-    hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(kRebinBlock), 0, stream, h->st + lo, h->st2 + lo, h->N, n, lo, (int)h->words,
+    hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(64), 0, stream, counts, offsets, nBlocks * kBins);
+    hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(64), 0, stream, h->st + lo, h->st2 + lo, h->N, n, lo, (int)h->words,
                        h->keys + lo, offsets, h->eid + lo, h->eid2 + lo, h->slotOf);
   }
   HIPCHK(hipGetLastError());
@@ -825,9 +842,13 @@ static int join_cohort_stream(blcd_handle h) {
 }
 // Re-bin lazily, right before a launch, once a chunk's worth of env steps has passed since the last sort - whoever cut the
 // steps into calls (one blcd_rollout, a caller that feeds 20-step rollouts to overlap a gather, or blcd_step in a loop).
-static int rebin_if_due(blcd_handle h) {
+static int rebin_if_due(blcd_handle h, int chunkNow = 0) {
   if (h->rebinEvery <= 0) return BLCD_OK;
-  int interval = h->rolloutChunk > 0 ? h->rolloutChunk : 20;
+  // inside the settling phase after a full reset the slots keep their (impact-time sorted) order: sorting by work class there
+  // packs the few environments that sweep to the end into the same waves, which then take 0.5 ms per env-step while the mixed
+  // waves take 0.15 (per-wave timers, profiles/r04_dropbox100k_chunk_waves.txt) - and a chunk lasts as long as its slowest wave
+  if (h->phase0Chunk > 0 && h->phase0NoSort && h->stepsSinceFullReset > 0 && h->stepsSinceFullReset < h->phase0Steps) return BLCD_OK;
+  int interval = chunkNow > 0 ? chunkNow : (h->rolloutChunk > 0 ? h->rolloutChunk : 20);
   if (interval < h->rebinEvery) interval = h->rebinEvery;
   if (h->stepsSinceRebin >= interval) return launch_rebin(h);
   return BLCD_OK;
@@ -1072,6 +1093,15 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
       int l = atoi(ev);
       if (l >= 1 && l <= 64) h->lanes = l;
     }
+    // The largest class is bound by the traffic of its scratch-resident constraint rows (26 KB per lane), and a scratch line
+    // holds one dword of each of a wave's 64 lanes: narrow waves waste most of every line.  Measured (Crab, ms per env-step of
+    // the batch): 20 000 envs as 1000 x 20 lanes 35.6, 625 x 32 lanes 27.7, 313 x 64 lanes (old 64-lane blocks) 29.0; 40 000
+    // envs 40.4-40.8 either way.  So: the widest waves the class's LDS blocks hold (kBigLanes = 32) once the batch gives every
+    // fourth SIMD such a wave; smaller batches keep the narrower-waves rule above (Crab-4096: 2.02e5 at 16 lanes, 1.87e5 at 32).
+    if (h->hostScene.nb > 7) {
+      if (!getenv("BLCD_LANES") && (long long)n_envs >= (long long)kBigLanes * (simds / 4)) h->lanes = kBigLanes;
+      if (h->lanes > kBigLanes) h->lanes = kBigLanes;
+    }
     // Re-binning by work class.  It pays when environments sleep / fly freely (no joints keep them awake) AND the batch
     // oversubscribes the SIMDs, so that total wave time is what counts: Bounce-100k 1.66e9 with, 1.09e9 without.  With at most
     // one wave per SIMD the launch lasts as long as its slowest wave, a wave's cost is convex in its number of heavy lanes, and
@@ -1090,6 +1120,11 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   // 5 / 10 / 15 / 20 - its waves are so uneven (5 of 64 lanes busy on average) that regrouping them twice as often pays; the circles
   // two-body class and the three-body class show no trend (Bounce2-100k, Object3-100k within noise or best at 20) and keep 20.
   if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 2 && kCfgs[h->cfg].sh == 0) h->rolloutChunk = 10;
+  if (const char* ev = getenv("BLCD_CHUNK0")) {
+    int a = 0, b = 0;
+    int c = 1;
+    if (sscanf(ev, "%d:%d:%d", &a, &b, &c) >= 2 && a >= 0 && b >= 0) h->phase0Steps = a, h->phase0Chunk = b, h->phase0NoSort = c;
+  }
 #ifdef BLCD_SCHED
   if (h->hostScene.nb <= 7) {
     if (const char* ev = getenv("BLCD_ASYNC")) h->asyncBudget = atoi(ev) > 0 ? atoi(ev) : 0;
@@ -1230,6 +1265,7 @@ int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int& b : h->sortedBlocks) b = 0;   // reset environments are awake wherever their slot is: the order is no longer a sorted one
+  if (!idxs) h->stepsSinceFullReset = 0;
   // A full reset of a circles-only scene restarts the re-bin clock: its first chunk runs best in sampled (well mixed) order
   // (Bounce-100k 1.67e9 vs 1.51e9 when the fresh states are sorted by predicted impact first).  Scenes with polygons keep the
   // clock running, so a sort that is due happens before their first chunk (Dropbox-100k 4.4e8 -> 5.0e8).
@@ -1358,6 +1394,7 @@ int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t s
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int& b : h->sortedBlocks) b = 0;   // reset environments are awake wherever their slot is: the order is no longer a sorted one
+  if (!idxs) h->stepsSinceFullReset = 0;
   if (!idxs && kCfgs[h->cfg].sh == 1) h->stepsSinceRebin = 0;
   return BLCD_OK;
 }
@@ -1490,10 +1527,12 @@ static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t*
       // re-bin) only.  Timed as ONE sequence on the handle's stream: e0 before the first launch, e1 after the other streams have joined.
       HIPCHK(hipEventRecord(h->evPool[0], h->stream));
       for (int k = 1; k < h->nCohorts; ++k) HIPCHK(hipStreamWaitEvent(h->cstream[k], h->evPool[0], 0));   // staged inputs (copied on the handle's stream) first
-      for (int t = 0; t < T; t += chunk) {
-        int c = T - t < chunk ? T - t : chunk;
+      for (int t = 0, c = 0; t < T; t += c) {
+        const int chunkNow = (h->phase0Chunk > 0 && h->stepsSinceFullReset < h->phase0Steps) ? h->phase0Chunk : chunk;
+        c = T - t < chunkNow ? T - t : chunkNow;
         const float* a = dAct ? (const float*)dAct + (size_t)t * h->N * nact : nullptr;
-        if ((rc = rebin_if_due(h))) return rc;
+        if ((rc = rebin_if_due(h, c))) return rc;
+        h->stepsSinceFullReset += c;
         for (int pass = 0; pass < h->yieldPasses; ++pass) {
           if (pass > 0 && (rc = launch_rebin(h, true))) return rc;      // suspended environments to the front, in dense waves
           for (int k = 0; k < h->nCohorts; ++k)

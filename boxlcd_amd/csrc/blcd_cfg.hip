@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
       if (slot >= nSlots) return;
     }
   } else {
-    if ((int)threadIdx.x >= lanes) return;
+    if ((int)threadIdx.x >= lanes || (int)threadIdx.x >= Env<NB, NJ, NP, SH, SCHED>::kMaxLanes) return;   // the host never asks for more lanes than the class's LDS blocks hold
     slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
     if (slot >= nSlots) return;
   }

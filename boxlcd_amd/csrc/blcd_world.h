@@ -305,26 +305,34 @@ struct ByteVec {
 // ids).  Small classes: plain per-thread arrays.  The largest class (17-20 bodies): columns of an LDS block [body][lane],
 // so that a run-time index is an LDS address (~100 cycles) instead of a scratch access behind 25 KB per lane of private
 // memory (the class's generic solver is bound by that latency).
-template <typename T, int N, bool LDS>
+// Lanes per wave of the largest class.  Its waves are bound by the latency of the scratch-resident generic solver (26 KB of
+// private memory per lane, one dependent ~500-cycle access per constraint row), so it wants SEVERAL waves per SIMD to hide
+// that latency - and its 210 registers allow two.  What stood in the way was the LDS block of the island's body columns
+// (6 x NB x 64 words = 30 KB per wave: four waves per CU): with at most BLCD_BIG_LANES environments per wave the block is
+// 6 x NB x 32 words = 15 KB, eight waves fit a CU (the host never launches this class with wider waves).
+#ifndef BLCD_BIG_LANES
+#define BLCD_BIG_LANES 32
+#endif
+template <typename T, int N, bool LDS, int LL = 64>
 struct BodyCol {
   T a[N];
   __device__ __forceinline__ T get(int i) const { return a[i]; }
   __device__ __forceinline__ void set(int i, const T& v) { a[i] = v; }
 };
 typedef __attribute__((address_space(3))) float LdsFloat;
-template <int N>
-struct BodyCol<float, N, true> {
-  LdsFloat* p;   // this lane's element of row 0; rows are 64 lanes apart
-  __device__ __forceinline__ float get(int i) const { return p[i * 64]; }
-  __device__ __forceinline__ void set(int i, float v) const { p[i * 64] = v; }
+template <int N, int LL>
+struct BodyCol<float, N, true, LL> {
+  LdsFloat* p;   // this lane's element of row 0; rows are LL lanes apart
+  __device__ __forceinline__ float get(int i) const { return p[i * LL]; }
+  __device__ __forceinline__ void set(int i, float v) const { p[i * LL] = v; }
 };
-template <int N>
-struct BodyCol<Vec2, N, true> {
-  LdsFloat* p;   // this lane's x of row 0; a row is 64 lanes x (x, y)
-  __device__ __forceinline__ Vec2 get(int i) const { return V2(p[i * 128], p[i * 128 + 1]); }
+template <int N, int LL>
+struct BodyCol<Vec2, N, true, LL> {
+  LdsFloat* p;   // this lane's x of row 0; a row is LL lanes x (x, y)
+  __device__ __forceinline__ Vec2 get(int i) const { return V2(p[i * 2 * LL], p[i * 2 * LL + 1]); }
   __device__ __forceinline__ void set(int i, const Vec2& v) const {
-    p[i * 128] = v.x;
-    p[i * 128 + 1] = v.y;
+    p[i * 2 * LL] = v.x;
+    p[i * 2 * LL + 1] = v.y;
   }
 };
 
@@ -460,8 +468,9 @@ struct Env {
   bool profOn;
   // --- island scratch ---
   static constexpr bool kGenLds = BLCD_GEN_LDS && NB > 7;
-  BodyCol<Vec2, NB, kGenLds> pc, pv;
-  BodyCol<float, NB, kGenLds> pa, pw;
+  static constexpr int kMaxLanes = NB > 7 ? BLCD_BIG_LANES : 64;   // environments per wave the kernel's LDS blocks are sized for
+  BodyCol<Vec2, NB, kGenLds, kMaxLanes> pc, pv;
+  BodyCol<float, NB, kGenLds, kMaxLanes> pa, pw;
   VC vc[kMaxC];
   ByteVec<NP> ic;
   // short-cycle detector for the velocity sweeps (islands without joints only)
@@ -499,13 +508,13 @@ struct Env {
     toiPending = false;
     islandedMask = 0;
     yieldMaxLanes = 0;
-    if constexpr (kGenLds) {   // 6 words x NB bodies x 64 lanes (30 KB for NB = 20)
-      __shared__ float blk[6 * NB * 64];
+    if constexpr (kGenLds) {   // 6 words x NB bodies x kMaxLanes lanes (15 KB for NB = 20, 32 lanes)
+      __shared__ float blk[6 * NB * kMaxLanes];
       LdsFloat* base = (LdsFloat*)blk;
       pc.p = base + 2 * threadIdx.x;
-      pv.p = base + 2 * NB * 64 + 2 * threadIdx.x;
-      pa.p = base + 4 * NB * 64 + threadIdx.x;
-      pw.p = base + 5 * NB * 64 + threadIdx.x;
+      pv.p = base + 2 * NB * kMaxLanes + 2 * threadIdx.x;
+      pa.p = base + 4 * NB * kMaxLanes + threadIdx.x;
+      pw.p = base + 5 * NB * kMaxLanes + threadIdx.x;
     }
     const int nb = S->nb, nj = S->nj, np = S->np;
     awakeMask = 0;
