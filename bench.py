@@ -222,7 +222,8 @@ def step_loop(env_name, N, local, steps, warmup=5):
   sec = time.perf_counter() - t0
   env.close()
   return {'value': steps * N / sec, 'unit': 'env-steps/s', 'env_steps_per_call': 1, 'calls': steps, 'ms_per_call': sec / steps * 1e3,
-          'note': 'BatchedWorldEnv.step_torch: blcd_step (one launch, one env-step) + blcd_get_obs (obs + LCD raster launch), device tensors in and out'}
+          'note': 'BatchedWorldEnv.step_torch = blcd_step_obs: one call, one launch (step_kernel writes the observation row and the frame), one stream '
+                  'synchronisation, device tensors in and out; round 3 issued blcd_step + blcd_get_obs (two launches, four synchronisations)'}
 
 
 def wire_model(world, N, T, d, mode, step_s_per_rollout):

@@ -22,6 +22,7 @@ SYMBOLS = {
     'blcd_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_set_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'blcd_step_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'blcd_reset_sampled': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_int32]),
     'blcd_sample_reseed': (C.c_int, [C.c_void_p]),
     'blcd_sample_set_base': (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -190,6 +191,13 @@ class Handle:
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (self.n, self.n_act), actions.shape
     _check(self.lib.blcd_step(self._h, _ptr(actions), int(n_steps)))
+
+  def step_obs(self, actions, fs, lcd):
+    """blcd_step_obs: one env-step + float32 observations + LCD into fs / lcd (numpy or torch, host or device), one sync"""
+    if actions is not None and not hasattr(actions, 'data_ptr'):
+      actions = np.ascontiguousarray(actions, dtype=np.float32)
+      assert actions.shape == (self.n, self.n_act), actions.shape
+    _check(self.lib.blcd_step_obs(self._h, _ptr(actions), _ptr(fs), _ptr(lcd)))
 
   def reset_sampled(self, idxs, seed, ops):
     """blcd_reset_sampled: reset environments idxs (None = all) from the device-side counter-based sampler"""

@@ -646,7 +646,8 @@ struct blcd_handle_s {
   int lastLaunches = 0;
   // staging
   void* stage[4] = {nullptr, nullptr, nullptr, nullptr};
-  int* dFaultAny = nullptr;  // device flag raised by step_kernel when an environment is faulted
+  int* dFaultAny = nullptr;  // flag raised by step_kernel when an environment is faulted: device view of ...
+  volatile int* hFaultAny = nullptr;   // ... one int of pinned, host-coherent memory: the host reads it after a stream synchronisation instead of copying it back (one round trip less per call)
   unsigned long long* dSchedStats = nullptr;   // blcd_sched_stats
   int* dEpisode = nullptr;                     // blcd_reset_sampled: per-environment reset count; staging of the sampled poses / shapes
   uint64_t envIdBase = 0;                      // blcd_sample_set_base: global id of this handle's environment 0
@@ -1038,10 +1039,15 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipSetDevice(device));
   { int rcS = acquire_stream(device, &h->stream); if (rcS) return rcS; }
   HIPCHK(hipEventCreate(&h->ev0));
-  HIPCHK(hipMalloc((void**)&h->dFaultAny, sizeof(int)));
+  {
+    void* hp = nullptr;
+    HIPCHK(hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped));
+    *(int*)hp = 0;
+    h->hFaultAny = (volatile int*)hp;
+    HIPCHK(hipHostGetDevicePointer((void**)&h->dFaultAny, hp, 0));
+  }
   HIPCHK(hipMalloc((void**)&h->dSchedStats, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(h->dSchedStats, 0, 8 * sizeof(unsigned long long), h->stream));
-  HIPCHK(hipMemsetAsync(h->dFaultAny, 0, sizeof(int), h->stream));
   HIPCHK(hipEventCreate(&h->ev1));
   HIPCHK(hipMalloc((void**)&h->dScene, sizeof(DevScene)));
   HIPCHK(hipMemcpy(h->dScene, &h->hostScene, sizeof(DevScene), hipMemcpyHostToDevice));
@@ -1200,7 +1206,7 @@ int blcd_destroy(blcd_handle h) {
     }
     if (h->evJoin[c]) (void)hipEventDestroy(h->evJoin[c]);
   }
-  if (h->dFaultAny) (void)hipFree(h->dFaultAny);
+  if (h->hFaultAny) (void)hipHostFree((void*)h->hFaultAny);
   if (h->dSchedStats) (void)hipFree(h->dSchedStats);
   for (void* q : {(void*)h->dEpisode, (void*)h->dSampleOps, (void*)h->dSamplePoses, (void*)h->dSampleSel})
     if (q) (void)hipFree(q);
@@ -1415,13 +1421,11 @@ int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* p
   return BLCD_OK;
 }
 
-// after the stream has drained: did any environment end the launch sequence with a fault flag?  (the flag is re-armed)
+// after the streams have drained (the caller has synchronised them): did any environment end the launch sequence with a fault flag?
+// (the flag is re-armed)
 static int fault_status(blcd_handle h) {
-  int any = 0;
-  HIPCHK(hipMemcpyAsync(&any, h->dFaultAny, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (!any) return BLCD_OK;
-  HIPCHK(hipMemsetAsync(h->dFaultAny, 0, sizeof(int), h->stream));
+  if (!*h->hFaultAny) return BLCD_OK;
+  *h->hFaultAny = 0;
   return fail(BLCD_ERR_ENV_FAULT, "an environment tripped a device guard (NaN state / ellipse outside the span table / island overflow): "
                                   "the step completed; read blcd_get_faults and reset the flagged environments");
 }
@@ -1438,6 +1442,37 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
   if ((rc = join_cohort_stream(h))) return rc;
   if ((rc = launch_step(h, (const float*)dAct, n_steps, 0, 0))) return rc;
   h->stepsSinceRebin += n_steps;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipEventElapsedTime(&h->lastMs, h->ev0, h->ev1));
+  return fault_status(h);
+}
+
+// One env-step and its observation in ONE call with ONE stream synchronisation: the call shape of a policy in the loop
+// (research/rl/ppo.py:127-133 `o, r, d, _ = env.step(a)`; async_vector_env.py:191-242 returns the observations with the step).
+int blcd_step_obs(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_step_obs: bad handle");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t obsBytes = (size_t)h->N * h->hostScene.nobs * sizeof(float), lcdBytes = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW;
+  const void* dAct;
+  void *dObs, *dLcd;
+  int rc;
+  if ((rc = in_ptr(h, 0, actions, (size_t)h->N * h->hostScene.nact * sizeof(float), &dAct))) return rc;
+  if ((rc = out_ptr(h, 1, full_state, obsBytes, &dObs))) return rc;
+  if ((rc = out_ptr(h, 2, lcd, lcdBytes, &dLcd))) return rc;
+  h->lastLaunches = 0;
+  if ((rc = rebin_if_due(h))) return rc;
+  if ((rc = join_cohort_stream(h))) return rc;
+  const bool fused = (h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0 && (dObs || dLcd);
+  if (fused) {
+    // the rollout's kernel path with T = 1: step_kernel writes the observation row and the frame itself
+    if ((rc = launch_step(h, (const float*)dAct, 1, 0, 0, nullptr, nullptr, (long long)h->N * h->hostScene.nact, (uint8_t*)dLcd, (float*)dObs))) return rc;
+  } else {
+    if ((rc = launch_step(h, (const float*)dAct, 1, 0, 0))) return rc;
+    if ((dObs || dLcd) && (rc = launch_obs<float>(h, (float*)dObs, (uint8_t*)dLcd))) return rc;
+  }
+  h->stepsSinceRebin += 1;
+  if (full_state && dObs != full_state) HIPCHK(hipMemcpyAsync(full_state, dObs, obsBytes, hipMemcpyDeviceToHost, h->stream));
+  if (lcd && dLcd != lcd) HIPCHK(hipMemcpyAsync(lcd, dLcd, lcdBytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipEventElapsedTime(&h->lastMs, h->ev0, h->ev1));
   return fault_status(h);

@@ -482,13 +482,17 @@ class BatchedWorldEnv(_EnvSpec):
     proprio = fs[:, self.pobs_idxs] if self.pobs_size != 0 else np.zeros((self.num_envs, 1), np.float32)
     return {'full_state': fs, 'proprio': proprio, 'lcd': lcd.astype(bool)}
 
-  def _step_handle(self, a):
-    """blcd_step completes the step for EVERY environment and then reports BLCD_ERR_ENV_FAULT if any environment carries a
-    device fault flag (contact-slot overflow, non-finite state).  One bad environment must not abort a 100k batch: the
-    bookkeeping goes on, the flags stay readable through `faults()` / `infos[i]['fault']` until those envs are reset."""
+  def _step_handle(self, a, fs=None, lcd=None):
+    """blcd_step / blcd_step_obs complete the step for EVERY environment and then report BLCD_ERR_ENV_FAULT if any environment
+    carries a device fault flag (contact-slot overflow, non-finite state).  One bad environment must not abort a 100k batch: the
+    bookkeeping goes on, the flags stay readable through `faults()` / `infos[i]['fault']` until those envs are reset.
+    With fs / lcd buffers the observation comes back with the step (one call, one stream synchronisation)."""
     from ._lib import EnvFaultError
     try:
-      self._handle().step(a, 1)
+      if fs is None and lcd is None:
+        self._handle().step(a, 1)
+      else:
+        self._handle().step_obs(a, fs, lcd)
       self._any_fault = False
     except EnvFaultError:
       self._any_fault = True
@@ -499,14 +503,18 @@ class BatchedWorldEnv(_EnvSpec):
 
   def step(self, actions):
     a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.act_size))
-    self._step_handle(a)
+    d = self.scene.desc
+    fs = np.zeros((self.num_envs, self.obs_size), np.float32)
+    lcd = np.zeros((self.num_envs, d.lcd_h, d.lcd_w), np.uint8)
+    self._step_handle(a, fs, lcd)
     self.ep_t += 1
     done = self.ep_t >= self.G.ep_len
-    infos = [{'timeout': bool(d)} for d in done]
+    infos = [{'timeout': bool(d_)} for d_ in done]
     if self._any_fault:
       for i in np.nonzero(self.faults())[0]:
         infos[int(i)]['fault'] = True
-    return self._obs(), np.zeros(self.num_envs, np.float64), done, infos
+    proprio = fs[:, self.pobs_idxs] if self.pobs_size != 0 else np.zeros((self.num_envs, 1), np.float32)
+    return {'full_state': fs, 'proprio': proprio, 'lcd': lcd.astype(bool)}, np.zeros(self.num_envs, np.float64), done, infos
 
   # ---- device-resident surface: torch CUDA tensors in and out, no host copies, no per-env Python objects -----------------
   # What the reference's GPU-side consumers loop over (research/rl/ppo.py:127-133 `o, r, d, info = env.step(a)`,
@@ -543,15 +551,18 @@ class BatchedWorldEnv(_EnvSpec):
 
   def step_torch(self, actions):
     """step(actions) on CUDA tensors: actions f32 [N, act] on the device -> (obs dict of tensors, rew f64 [N] zeros,
-    done bool [N], timeout bool [N]) - one kernel launch + one obs/raster launch, nothing crosses PCIe."""
+    done bool [N], timeout bool [N]) - ONE call (blcd_step_obs: the step kernel writes the observation row and the frame itself),
+    one stream synchronisation, nothing crosses PCIe."""
     tb = self._torch_bufs()
     a = actions.contiguous() if actions.dtype == tb['full_state'].dtype else actions.float().contiguous()
     assert a.is_cuda and tuple(a.shape) == (self.num_envs, self.act_size)
-    self._step_handle(a)          # a faulted environment does not abort the batch: see faults()
+    self._step_handle(a, tb['full_state'], tb['lcd'])          # blcd_step_obs; a faulted environment does not abort the batch: see faults()
     tb['ep_t'] += 1
     self.ep_t += 1
     done = tb['ep_t'] >= int(self.G.ep_len)
-    return self._obs_torch(), tb['rew'], done, done
+    fs = tb['full_state']
+    proprio = fs[:, tb['pidx']] if self.pobs_size != 0 else fs.new_zeros((self.num_envs, 1))
+    return {'full_state': fs, 'proprio': proprio, 'lcd': tb['lcd']}, tb['rew'], done, done
 
   def lcd_render(self, width=None, height=None, lcd_mode='1'):
     """Batched reference world_env.py:460-512: bool [N, H, W] for '1', uint8 [N, H, W, 3] for 'RGB', any canvas size."""

@@ -160,6 +160,12 @@ int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* p
  * Returns BLCD_ERR_ENV_FAULT (after completing the step) when any environment carries a fault flag: see blcd_get_faults. */
 int blcd_step(blcd_handle h, const float* actions, int32_t n_steps);
 
+/* blcd_step(actions, 1) + blcd_get_obs(float32) as ONE call with one stream synchronisation - `obs, rew, done, info =
+ * venv.step(actions)` as the reference's policy loops issue it (research/rl/ppo.py:127-133, rl/sac.py:200-214;
+ * async_vector_env.py:191-242 returns the observations with the step).  full_state float32 [n_envs][n_obs], lcd uint8
+ * [n_envs][lcd_h][lcd_w]; either may be NULL; host|device.  Same results as the two calls (tests/test_gpu_api.py). */
+int blcd_step_obs(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd);
+
 /* Fused rollout, replaces the inner loop of research/data.py:56-61 (`for j in range(ep_len): venv.step(act)`):
  * T env-steps with per-step actions [T][n_envs][n_act]; per-step outputs (any may be NULL):
  * lcd_out uint8 [T][n_envs][lcd_h][lcd_w], obs_out float32 [T][n_envs][n_obs].  All host|device.

@@ -194,6 +194,39 @@ def test_device_resident_vector_env():
   a.close(); b.close()
 
 
+@pytest.mark.parametrize('name,n', [('Bounce', 70_000), ('Dropbox', 1000), ('Object2', 333), ('Urchin', 100), ('Crab', 40)])
+def test_step_obs_equals_step_then_get_obs(name, n):
+  """blcd_step_obs (one call, one synchronisation: the step kernel writes the observation row and the frame itself) against
+  blcd_step + blcd_get_obs on an identically started twin, every step of 30, host and device buffers; final state vs the oracle.
+  Bounce-70k is a re-binned two-cohort batch, Crab the 32-row class (separate raster kernel for classes <= 7 bodies only)."""
+  import torch
+  T = 30
+  env = B.BatchedWorldEnv(name, n, seed=17)
+  poses, sel = env.sample_initial(n)
+  acts = env.sample_actions(T)
+  d = env.scene.desc
+  ha, hb = Handle(d, n, 0), Handle(d, n, 0)
+  ha.reset(None, poses, sel); hb.reset(None, poses, sel)
+  fs = np.zeros((n, d.n_obs), np.float32); lcd = np.zeros((n, d.lcd_h, d.lcd_w), np.uint8)
+  fs_t = torch.zeros((n, d.n_obs), dtype=torch.float32, device='cuda'); lcd_t = torch.zeros((n, d.lcd_h, d.lcd_w), dtype=torch.uint8, device='cuda')
+  for t in range(T):
+    if t % 2 == 0:
+      ha.step_obs(acts[t], fs, lcd)
+    else:
+      ha.step_obs(torch.as_tensor(acts[t]).cuda(), fs_t, lcd_t)
+      fs, lcd = fs_t.cpu().numpy(), lcd_t.cpu().numpy()
+    hb.step(acts[t], 1)
+    fs2, lcd2 = hb.get_obs(np.float32)
+    assert (fs == fs2).all() and (lcd == lcd2).all(), t
+    fs, lcd = np.zeros_like(fs2), np.zeros_like(lcd2)
+  assert (ha.debug_dump()[0] == hb.debug_dump()[0]).all()
+  idx = np.arange(min(n, 64))
+  _, _, olcd, ost = pyb2o.rollout(d, poses[idx], sel[idx], acts[:, idx], T, threads=8)
+  assert (ost == ha.debug_dump()[0][idx]).all() and (olcd == lcd2[idx]).all()
+  ha.step_obs(None, None, None)      # no outputs: a plain step
+  ha.close(); hb.close()
+
+
 def test_bit_transport_of_lcd_frames():
   """blcd_pack_bits / blcd_unpack_bits (the 1-bit wire format of the multi-GPU gather): exact round trip, numpy bit order."""
   import torch
