@@ -226,7 +226,7 @@ def step_loop(env_name, N, local, steps, warmup=5):
                   'synchronisation, device tensors in and out; round 3 issued blcd_step + blcd_get_obs (two launches, four synchronisations)'}
 
 
-def wire_model(world, N, T, d, mode, step_s_per_rollout):
+def wire_model(world, N, T, d, mode, step_s_per_rollout, weak=True):
   """Bytes a rollout puts on xGMI and what that predicts, so that the first real SCALE run can be checked against a number:
   LCD frames travel at 1 bit per pixel, observations as float32.  xGMI is point-to-point, 7 links x ~153 GB/s per GPU
   (MI355X_MICROARCH.md): a DIRECT all-gather uses all 7 links at once (each peer's shard arrives over its own link); a single
@@ -238,11 +238,13 @@ def wire_model(world, N, T, d, mode, step_s_per_rollout):
   t_direct = per_rank / LINK
   t_ring = (world - 1) * per_rank / LINK
   eff = lambda tg: step_s_per_rollout / max(step_s_per_rollout, tg) if step_s_per_rollout > 0 else None
-  return {'bytes_sent_per_rank_per_rollout': per_rank, 'bytes_received_per_rank_per_rollout': recv if mode == 'all' else '(world-1) x per_rank on rank 0 only',
-          'link_GBps': LINK / 1e9, 'gather_s_direct_all_links': t_direct, 'gather_s_single_ring': t_ring, 'stepping_s_per_rollout_measured': step_s_per_rollout,
-          'predicted_efficiency_direct': eff(t_direct), 'predicted_efficiency_single_ring': eff(t_ring),
-          'predicted_at_8_ranks': {'gather_s_direct': per_rank / LINK, 'gather_s_single_ring': 7 * per_rank / LINK,
-                                   'efficiency_direct': eff(per_rank / LINK), 'efficiency_single_ring': eff(7 * per_rank / LINK)}}
+  out = {'bytes_sent_per_rank_per_rollout': per_rank, 'bytes_received_per_rank_per_rollout': recv if mode == 'all' else '(world-1) x per_rank on rank 0 only',
+         'link_GBps': LINK / 1e9, 'gather_s_direct_all_links': t_direct, 'gather_s_single_ring': t_ring, 'stepping_s_per_rollout_measured': step_s_per_rollout,
+         'predicted_efficiency_direct': eff(t_direct), 'predicted_efficiency_single_ring': eff(t_ring)}
+  if weak:   # weak scaling keeps the shard size: the same shard's gather over 7 peers against the same stepping time
+    out['predicted_at_8_ranks'] = {'gather_s_direct': per_rank / LINK, 'gather_s_single_ring': 7 * per_rank / LINK,
+                                   'efficiency_direct': eff(per_rank / LINK), 'efficiency_single_ring': eff(7 * per_rank / LINK)}
+  return out
 
 
 def time_rollouts(w, rollouts, warmup, bdist, torch, gather=True):
@@ -363,7 +365,7 @@ def main():
         cfgs[f'{name}-{n_total}-sharded-x{world}'] = {
             'value': rolls * T * n_r * world / sec, 'unit': 'env-steps/s', 'scaling': 'strong', 'envs_total': n_r * world, 'envs_per_gpu': n_r, 'rollouts': rolls,
             'seconds': sec, 'gather': args.gather, 'stepping_only': {'value': rolls * T * n_r * world / sec2, 'unit': 'env-steps/s', 'seconds': sec2},
-            'wire': wire_model(world, n_r, T, ww.d, args.gather, sec2 / rolls), 'faulted_envs': int((ww.h.faults() != 0).sum())}
+            'wire': wire_model(world, n_r, T, ww.d, args.gather, sec2 / rolls, weak=False), 'faulted_envs': int((ww.h.faults() != 0).sum())}
       ww.close()
       del ww
       torch.cuda.empty_cache()
