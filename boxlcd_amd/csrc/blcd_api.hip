@@ -629,6 +629,7 @@ struct blcd_handle_s {
   // rounds per chunk - unless the chunks are short enough for the two cohorts to interleave.  For the first
   // phase0Steps env-steps after a full reset the chunks are phase0Chunk long (0 = no such phase).  BLCD_CHUNK0=<steps>:<len>.
   int phase0Steps = 0, phase0Chunk = 0, phase0NoSort = 1;
+  int cohortSwap = 0;
   long long stepsSinceFullReset = 1 << 30;
   // Cohorts: an oversubscribed joint-free batch is stepped as two slot ranges on two streams, each re-binned within itself, so
   // that neither waits at a chunk boundary for the slowest wave of the whole batch.  cohortLo[c] ..
@@ -661,6 +662,11 @@ struct blcd_handle_s {
   size_t stageBytes[4] = {0, 0, 0, 0};
   int cfg = -1;
 };
+
+static inline hipStream_t cohort_stream(blcd_handle h, int c) {
+  if (h->cohortSwap && h->nCohorts >= 2 && c <= 1) c = 1 - c;
+  return c > 0 ? h->cstream[c] : h->stream;
+}
 
 static int ensure_stage(blcd_handle h, int k, size_t bytes) {
   if (h->stageBytes[k] >= bytes) return BLCD_OK;
@@ -722,6 +728,8 @@ static int out_done(blcd_handle h, int k, void* p, size_t bytes, void* dev) {
 }
 
 static FILE* g_launchLog = nullptr;   // diagnostic: see launch_step
+// the stream cohort c runs on: cohort 0 on the handle's stream, cohort c > 0 on cstream[c] (BLCD_COHORT_SWAP: experiment, cohorts 0 and 1 exchanged)
+static inline hipStream_t cohort_stream(blcd_handle h, int c);
 constexpr int kBigLanes = BLCD_BIG_LANES;   // blcd_world.h
 
 // ---- template dispatch over (max bodies, max joints, max pair slots) -------------------------------------
@@ -759,7 +767,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   const int lanes = h->lanes;
   const int lo = cohort < 0 ? 0 : h->cohortLo[cohort];
   const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
-  hipStream_t stream = cohort > 0 ? h->cstream[cohort] : h->stream;
+  hipStream_t stream = cohort < 0 ? h->stream : cohort_stream(h, cohort);
   dim3 grid((n + lanes - 1) / lanes), block(kBlock);
   // two wave widths (see step_kernel): only for the plain kernel on a slot order that the last sort produced for exactly this range
   const int* heavyEnd = nullptr;
@@ -819,7 +827,7 @@ static int launch_rebin(blcd_handle h, bool midChunk = false, int tEnd = 0) {
   const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;   // room for every cohort's block counts (rounding)
   for (int c = 0; c < h->nCohorts; ++c) {
     const int lo = h->cohortLo[c], n = h->cohortLo[c + 1] - lo;
-    hipStream_t stream = c > 0 ? h->cstream[c] : h->stream;
+    hipStream_t stream = cohort_stream(h, c);
     const int nBlocks = (n + kRebinBlock - 1) / kRebinBlock;
     int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
     int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
@@ -1126,6 +1134,7 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   // 5 / 10 / 15 / 20 - its waves are so uneven (5 of 64 lanes busy on average) that regrouping them twice as often pays; the circles
   // two-body class and the three-body class show no trend (Bounce2-100k, Object3-100k within noise or best at 20) and keep 20.
   if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 2 && kCfgs[h->cfg].sh == 0) h->rolloutChunk = 10;
+  if (const char* ev = getenv("BLCD_COHORT_SWAP")) h->cohortSwap = atoi(ev) != 0;
   if (const char* ev = getenv("BLCD_CHUNK0")) {
     int a = 0, b = 0;
     int c = 1;

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
   // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
   int slot;
+  bool valid = true;   // false: a shadow lane of the ragged last wave (computes, never stores)
   if (heavyEnd) {
     // Two wave widths in one launch (re-binned batches).  The slot sort puts the environments that are not asleep first
     // (*heavyEnd of them, heaviest first).  While they oversubscribe the SIMDs, full waves are best (total wave time counts); once
@@ -72,7 +73,17 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   } else {
     if ((int)threadIdx.x >= lanes || (int)threadIdx.x >= Env<NB, NJ, NP, SH, SCHED>::kMaxLanes) return;   // the host never asks for more lanes than the class's LDS blocks hold
     slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
-    if (slot >= nSlots) return;
+    if (slot >= nSlots) {
+      // The ragged last wave of a 64-lane launch (100 000 environments = 1 562 waves + 32 lanes).  Its missing lanes used to
+      // exit here, which sent the wave down the per-lane emission path (a frame needs all 64 lanes to write it, see below): full
+      // raster + float64 observation glue on EVERY step, no reuse for environments at rest - one such wave was the whole
+      // 1.7 ms of a sleeping Dropbox chunk (0.47 ms without it; profiles/r04_dropbox100k_rest_timeline.txt).  Instead the
+      // missing lanes shadow the range's last environment: same inputs, same arithmetic, no store (`valid`), so every wave
+      // of the launch is a full one.  The scheduler's kernel and narrower waves keep the early exit.
+      if (SCHED || lanes != 64 || nSlots < 1) return;
+      slot = nSlots - 1;
+      valid = false;
+    }
   }
   const int e = eid[slot];
   using EnvT = Env<NB, NJ, NP, SH, SCHED>;
@@ -112,36 +123,41 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
             *sel = env.sel[bi];
           };
           bool ok;
+          float* const obsRowV = (obsOut && valid) ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr;   // this lane's observation row (shadow lanes: none)
           if (lcdOut && lcdBits && S->lcdW == 16) {
             // 16x16 frames at one bit per pixel: 32 B per environment, straight from the row masks (complemented: 1 = background)
             uint4* o = reinterpret_cast<uint4*>(lcdOut + ((size_t)t * N + e) * 32);
             ok = true;
             if (reuse) {
-              const uint4* prev = reinterpret_cast<const uint4*>(lcdOut + ((size_t)(t - 1) * N + e) * 32);
-              o[0] = prev[0];
-              o[1] = prev[1];
-              copyObsRow(obsOut, t, N, e, S->nobs);
+              if (valid) {
+                const uint4* prev = reinterpret_cast<const uint4*>(lcdOut + ((size_t)(t - 1) * N + e) * 32);
+                o[0] = prev[0];
+                o[1] = prev[1];
+                copyObsRow(obsOut, t, N, e, S->nobs);
+              }
             } else {
               uint32_t rows[16];
-              ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
+              ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowV, nullptr, rows);
               uint32_t w[8];
 #pragma unroll
               for (int j = 0; j < 8; ++j) w[j] = (~rows[2 * j] & 0xffffu) | (~rows[2 * j + 1] << 16);
-              o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-              o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+              if (valid) {
+                o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+              }
             }
             emitted = true;
-          } else if (lcdOut && S->lcdW == 16 && __ballot(1) == ~0ull) {   // full waves only: a frame needs all 64 lanes to write it
+          } else if (lcdOut && S->lcdW == 16 && __ballot(1) == ~0ull) {   // full waves only (shadow lanes included): a frame needs all 64 lanes to write it
             // 16x16 frames: 256 B = one dword per lane.  Writing each lane's own frame row by row makes every store touch 64
             // different cache lines; instead the lanes park their 16 row masks in LDS and the wave writes one whole frame per
             // store instruction (fully coalesced), frame k being the environment held by lane k.
             const int lane = (int)threadIdx.x;
             ok = true;
             if (reuse) {   // this lane's rows of the previous step are still in LDS (nothing else lives in that block for joint-free classes)
-              copyObsRow(obsOut, t, N, e, S->nobs);
+              if (valid) copyObsRow(obsOut, t, N, e, S->nobs);
             } else {
               uint32_t rows[16];
-              ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr, nullptr, rows);
+              ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowV, nullptr, rows);
 #pragma unroll
               for (int y = 0; y < 16; ++y) ldsRows[lane * 17 + y] = rows[y];
             }
@@ -151,20 +167,23 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             uint8_t* frames = lcdOut + (size_t)t * N * lcdRow;
             const int row = lane >> 2, x0 = (lane & 3) * 4;   // this lane's 4 pixels of any frame
-            for (int k = 0; k < 64; ++k) {
+            const int nFrames = __popcll(__ballot(valid));      // shadow lanes are the wave's last lanes: their frames are not written
+            for (int k = 0; k < nFrames; ++k) {
               const int ek = __builtin_amdgcn_readlane(e, k);
               const uint32_t m = ldsRows[k * 17 + row];
               const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
               *reinterpret_cast<uint32_t*>(frames + (size_t)ek * 256 + 4 * lane) = px;
             }
             __builtin_amdgcn_wave_barrier();
-          } else {
+          } else if (valid) {
             float* obsRowOut = obsOut ? obsOut + ((size_t)t * N + e) * S->nobs : nullptr;
             uint8_t* lcdRowOut = lcdOut ? lcdOut + ((size_t)t * N + e) * lcdRow : nullptr;
             bool tall = false;
             if constexpr (NB > 7) tall = S->lcdH == 32;   // 32-row LCDs (Crab, CrabCube, SpiderCube) only occur in the largest class
             if (tall) ok = emit_env<32, uint64_t, float, false>(S, body, obsRowOut, lcdRowOut, nullptr, lcdBits != 0);
             else ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowOut, lcdRowOut, nullptr, lcdBits != 0);
+          } else {
+            ok = true;
           }
           if (!ok) env.fault |= FAULT_ELLIPSE;
         }
@@ -174,6 +193,7 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
       for (int k = 0; k < nWorldSteps; ++k) env.worldStep();
     }
     env.checkFault();
+    if (!valid) return;   // shadow lane: the environment's own lane stores
     if (env.fault && faultAny) *faultAny = 1;
     env.store(st, N, slot);
     if (kWaveTimes && waveTimes) {

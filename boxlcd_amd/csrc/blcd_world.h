@@ -994,6 +994,18 @@ struct Env {
   // b2ContactSolver
   // ------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void csInit(int count, bool warmStarting, float dtRatio) {
+#ifndef BLCD_NO_KILL
+    // End the live ranges of the previous island's constraint rows here.  The loops below define rows / points conditionally
+    // (i < count, j < pointCount), so without this every word of the register-resident vc[] stays live from one island solve
+    // to the next - through collide and the TOI root finder - as the "else" value of a phi: the general one-body kernel needed
+    // 512 registers (+ 18 spills) and 668 spills under a 256-register bound; with the rows value-initialised here it needs 411,
+    // and 177 spills (none in a hot loop) under the 256-register bound that lets two waves share a SIMD.
+    // Bit-neutral: every word read after this point is written first (it was before, or the old code read a stale row).
+    if constexpr (kMaxC <= 4) {
+#pragma unroll
+      for (int i = 0; i < kMaxC; ++i) vc[i] = VC{};
+    }
+#endif
 #pragma unroll kU
     for (int i = 0; i < kMaxC; ++i) {
       if (i >= count) break;
@@ -2386,6 +2398,19 @@ struct Env {
       findNewContacts(false);
       return false;
     }
+#ifndef BLCD_NO_KILL
+    // the generic island's per-body working arrays (register-resident for <= 7 bodies) are written for island members only:
+    // value-initialise them here so that last step's values do not stay live through collide and the TOI pass (see csInit)
+    if constexpr (!kGenLds && !SCHED) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        pc.a[i] = V2(0.0f, 0.0f);
+        pv.a[i] = V2(0.0f, 0.0f);
+        pa.a[i] = 0.0f;
+        pw.a[i] = 0.0f;
+      }
+    }
+#endif
     const int nb = S->nb;
     uint32_t bodyIsland = 0, jointIsland = 0;
     bool anyYield = false;
