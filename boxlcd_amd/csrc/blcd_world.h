@@ -1001,7 +1001,9 @@ struct Env {
     // 512 registers (+ 18 spills) and 668 spills under a 256-register bound; with the rows value-initialised here it needs 411,
     // and 177 spills (none in a hot loop) under the 256-register bound that lets two waves share a SIMD.
     // Bit-neutral: every word read after this point is written first (it was before, or the old code read a stale row).
-    if constexpr (kMaxC <= 4) {
+    // (not for the circles-only class: it fits two waves anyway - 212 registers - and its islands settle in 2-5 sweeps, so the
+    // ~70 extra moves per island solve cost Bounce-100k 3 %)
+    if constexpr (kMaxC <= 4 && !kCirc) {
 #pragma unroll
       for (int i = 0; i < kMaxC; ++i) vc[i] = VC{};
     }
