@@ -830,6 +830,14 @@ struct RegIsland {
   // state row for the short-cycle detector (joint-free islands): all body velocities + contact impulses
   static constexpr int kCycP = NB <= 3 ? 4 : 2;
   static constexpr int kCycW = 3 * NB + 4 * NCR;
+#ifndef BLCD_CYC_REF_LDS
+#define BLCD_CYC_REF_LDS 1
+#endif
+  static constexpr bool kCycRefLds = BLCD_CYC_REF_LDS && NB == 2;   // Brent's reference row in LDS (velocitySweeps); the three-body class loses 5 % with it (Object3-100k 2.44e7 -> 2.31e7)
+  static __device__ __forceinline__ float* cycRefLds() {
+    __shared__ float blk[kCycRefLds ? kCycW * 64 : 1];
+    return blk;
+  }
   struct CycRow {
     float v[kCycW];
   };
@@ -900,6 +908,13 @@ struct RegIsland {
     const bool watch = nj == 0 && nc > 0;
 #ifndef BLCD_CYC_WINDOW
     constexpr int kCycWatch = BLCD_CYC_WATCH;
+#if BLCD_CYC_REF_LDS
+    // The reference row lives in the wave's LDS ([word][lane]) for the two-body classes: it is written after sweeps 1, 2, 4,
+    // .. and read only when a digest matches, but as kCycW (22) registers that stay live across the whole watched loop it
+    // was what the 256-register build of the two-body class spilled - 44 scratch instructions in every one of the first 48
+    // sweeps (kept ISA, tools/spill_loops.py).  The main island and the TOI mini-island never sweep at the same time: one block.
+    float* const refL = kCycRefLds ? cycRefLds() + threadIdx.x : nullptr;
+#endif
     CycRow ref;
     uint32_t refDig = 0;
     int refIt = -1, last = velIters - 1;
@@ -941,8 +956,16 @@ struct RegIsland {
         for (int q = 0; q < kCycW; ++q) dig = dig * 31u + __float_as_uint(cur.v[q] + 0.0f);
         if (refIt >= 0 && dig == refDig) {
           bool same = true;
+#if BLCD_CYC_REF_LDS
+          if constexpr (kCycRefLds) {
 #pragma unroll
-          for (int q = 0; q < kCycW; ++q) same = same && (ref.v[q] == cur.v[q]);
+            for (int q = 0; q < kCycW; ++q) same = same && (refL[64 * q] == cur.v[q]);
+          } else
+#endif
+          {
+#pragma unroll
+            for (int q = 0; q < kCycW; ++q) same = same && (ref.v[q] == cur.v[q]);
+          }
           if (same) {
             cycling = true;
             last = it + (velIters - 1 - it) % (it - refIt);
@@ -950,7 +973,15 @@ struct RegIsland {
           }
         }
         if (((it + 1) & it) == 0) {
-          ref = cur;
+#if BLCD_CYC_REF_LDS
+          if constexpr (kCycRefLds) {
+#pragma unroll
+            for (int q = 0; q < kCycW; ++q) refL[64 * q] = cur.v[q];
+          } else
+#endif
+          {
+            ref = cur;
+          }
           refDig = dig;
           refIt = it;
         }
