@@ -1129,7 +1129,10 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   // those fixed costs weigh more than the better grouping of a 20-step interval buys (200-step rollouts, tools/chunk_sweep.sh):
   // Bounce-100k 1.84e9 (20) -> 2.02e9 (50) -> 2.12e9 (100); Dropbox-100k 6.4e8 (20) -> 6.6e8 (40, 50) -> 6.4e8 (100).
   // Multi-body batches keep 20 (Object2-200k: 6.3e7 / 6.1e7 / 5.8e7 at 10 / 20 / 40).  Results do not depend on the chunking.
-  if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 1) h->rolloutChunk = kCfgs[h->cfg].sh == 1 ? 100 : 50;
+  // Round 4: with two co-resident waves per SIMD the general one-body class no longer runs its settling phase in two rounds, and the
+  // longer chunk wins there too: Dropbox-100k 1.01 / 1.15 / 1.20 / 1.24 / 1.26 / 1.30e9 at 30 / 40 / 50 / 67 / 100 / 200 (the circles-only
+  // class keeps 100: 2.04 / 2.10 / 1.94e9 at 50 / 100 / 200).
+  if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 1) h->rolloutChunk = kCfgs[h->cfg].sh == 1 ? 100 : 200;
   // The general two-body class after the cheaper cycle detection (round 3): Object2-200k 7.65e7 / 7.62e7 / 7.50e7 / 7.31e7 at
   // 5 / 10 / 15 / 20 - its waves are so uneven (5 of 64 lanes busy on average) that regrouping them twice as often pays; the circles
   // two-body class and the three-body class show no trend (Bounce2-100k, Object3-100k within noise or best at 20) and keep 20.
