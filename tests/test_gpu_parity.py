@@ -333,7 +333,12 @@ def test_cohorts_of_an_oversubscribed_batch_change_nothing(monkeypatch):
     env, poses, sel = parity.make_batch(name, n, 9)
     d = env.scene.desc
     res = []
-    for cohorts in ('1', '2'):
+    # + the round-4 placement knobs: three cohorts, settling-phase chunks without the sort, cohorts on exchanged streams
+    for cohorts, extra in (('1', {}), ('2', {}), ('3', {}), ('2', {'BLCD_CHUNK0': '30:7'}), ('2', {'BLCD_CHUNK0': '40:10:0', 'BLCD_COHORT_SWAP': '1'})):
+      for k in ('BLCD_CHUNK0', 'BLCD_COHORT_SWAP'):
+        monkeypatch.delenv(k, raising=False)
+      for k, v in extra.items():
+        monkeypatch.setenv(k, v)
       monkeypatch.setenv('BLCD_COHORTS', cohorts)
       h = Handle(d, n, 0)
       h.reset(None, poses, sel)
@@ -343,11 +348,12 @@ def test_cohorts_of_an_oversubscribed_batch_change_nothing(monkeypatch):
       h.step(None, 3)                                   # the single-stream path right after a cohort rollout
       res.append((lcd, obs, [x.copy() for x in h.debug_dump()], h.faults().copy()))
       h.close()
-    a, b = res
-    assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), name
-    for x, y in zip(a[2], b[2]):
-      assert (x == y).all(), name
-    assert (a[3] == 0).all() and (b[3] == 0).all()
+    a = res[0]
+    for b in res[1:]:
+      assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), name
+      for x, y in zip(a[2], b[2]):
+        assert (x == y).all(), name
+      assert (a[3] == 0).all() and (b[3] == 0).all()
 
 
 @pytest.mark.parametrize('n', [10, 64, 65, 130, 255])
