@@ -283,6 +283,53 @@ def test_chunk_gather_of_full_rollout_tensors_two_ranks():
   assert sorted(res) == [(0, True), (1, True)]
 
 
+def _rccl_rank(port, mode, q):
+  import os, torch
+  from boxlcd_amd import dist as bdist
+  os.environ.update(RANK='0', WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  try:
+    torch.cuda.set_device(0)
+    # a ONE-rank RCCL communicator (torch backend 'nccl'): the same ChunkGatherer calls bench.py --gpus N issues, on the real backend
+    torch.distributed.init_process_group(backend='nccl', rank=0, world_size=1, init_method=f'tcp://127.0.0.1:{port}')
+    Tc, n = 4, 96
+    g = bdist.ChunkGatherer(1, [torch.empty((Tc, n, 16, 16), dtype=torch.uint8, device='cuda'), torch.empty((Tc, n, 4), device='cuda')],
+                            binary=[True, False], mode=mode, rank=0)
+    ok = True
+    for chunk in range(3):
+      gen = torch.Generator(device='cuda'); gen.manual_seed(chunk)
+      lcd = (torch.rand((Tc, n, 16, 16), device='cuda', generator=gen) < 0.4).to(torch.uint8)
+      obs = torch.rand((Tc, n, 4), device='cuda', generator=gen)
+      g.gather([lcd, obs], producer=torch.cuda.current_stream())
+      g.finish()
+      gl, go = g.last()
+      ok = ok and bool((gl[0] == lcd).all()) and bool((go[0] == obs).all())
+    t = torch.tensor([3.5], dtype=torch.float64, device='cuda')
+    ok = ok and bdist.max_over_ranks(3.5) == 3.5
+    bdist.barrier()
+    q.put(('ok', ok))
+    torch.distributed.destroy_process_group()
+  except Exception as ex:      # report instead of hanging the parent on the queue
+    q.put(('error', repr(ex)))
+
+
+@pytest.mark.parametrize('mode', ['all', 'consumer'])
+def test_chunk_gather_on_the_rccl_backend_single_rank(mode):
+  """The gather path on its REAL backend: torch.distributed 'nccl' (= RCCL on ROCm) with a one-rank communicator on this one GPU -
+  `all_gather_into_tensor` / `gather` of bit-packed frames and float32 observations on the side stream, `max_over_ranks`, `barrier`,
+  exactly as `bench.py --gpus N` issues them.  (Two ranks cannot share a GPU under RCCL; the multi-rank data movement is the
+  driver's 8-GPU run, the two-rank logic is covered on gloo above.)"""
+  import socket
+  import torch.multiprocessing as mp
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  p = ctx.Process(target=_rccl_rank, args=(port, mode, q))
+  p.start()
+  res = q.get(timeout=240)
+  p.join(timeout=60)
+  assert res == ('ok', True), res
+
+
 @pytest.mark.parametrize('name,n', [('Bounce', 4096), ('Dropbox', 1000), ('LuxoBall', 300), ('Urchin', 257), ('Crab', 64)])
 def test_rollout_bits_unpacks_to_the_uint8_frames(name, n):
   """blcd_rollout_bits: the row masks the raster holds, one bit per pixel (north_star's "1-bit framebuffer"; `lcd` is a bool array
