@@ -237,6 +237,8 @@ __global__ void dump_kernel(const DevScene* __restrict__ S, const float* __restr
 constexpr int kBins = 51;   // + bins 0..2 (ahead of everything): environments suspended at a TOI event / in position iterations / in velocity sweeps
 constexpr int kPredictSteps = 32;
 constexpr int kRebinBlock = 256;
+// ints between two cohorts' count / offset tables (a multiple of four: the scan reads and writes int4)
+static inline size_t binTableStride(int nBlocksAll) { return ((size_t)nBlocksAll * kBins + 3) & ~(size_t)3; }
 
 __device__ inline int work_class1(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode);
 __device__ inline int work_class(const DevScene* __restrict__ S, const float* __restrict__ st, int N, int slot, int mode, int tEnd) {
@@ -322,12 +324,18 @@ __global__ __launch_bounds__(64) void rebin_hist_kernel(const DevScene* __restri
   if (threadIdx.x < kBins) counts[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];  // bin-major
 }
 
-// exclusive scan of counts[bin][block] in bin-major order: one wave, lane l owns a contiguous run of entries
+// exclusive scan of counts[bin][block] in bin-major order: one wave, lane l owns a contiguous run of entries (a multiple of four,
+// read and written as int4: the run is walked twice and every access is a dependent L1 hit otherwise)
 __global__ __launch_bounds__(64) void rebin_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int n) {
-  const int lane = threadIdx.x, per = (n + 63) / 64;
+  const int lane = threadIdx.x, per = (((n + 63) / 64) + 3) & ~3;
   const int lo = lane * per, hi = lo + per < n ? lo + per : n;
   int sum = 0;
-  for (int i = lo; i < hi; ++i) sum += counts[i];
+  int i = lo;
+  for (; i + 4 <= hi; i += 4) {
+    const int4 c = *reinterpret_cast<const int4*>(counts + i);
+    sum += (c.x + c.y) + (c.z + c.w);
+  }
+  for (; i < hi; ++i) sum += counts[i];
   int incl = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -335,44 +343,58 @@ __global__ __launch_bounds__(64) void rebin_scan_kernel(const int* __restrict__ 
     if (lane >= d) incl += v;
   }
   int acc = incl - sum;
-  for (int i = lo; i < hi; ++i) {
+  i = lo;
+  for (; i + 4 <= hi; i += 4) {
+    const int4 c = *reinterpret_cast<const int4*>(counts + i);
+    int4 o;
+    o.x = acc;
+    o.y = o.x + c.x;
+    o.z = o.y + c.y;
+    o.w = o.z + c.z;
+    acc = o.w + c.w;
+    *reinterpret_cast<int4*>(offsets + i) = o;
+  }
+  for (; i < hi; ++i) {
     const int c = counts[i];
     offsets[i] = acc;
     acc += c;
   }
 }
 
-// stable scatter: new slot = offset[bin][block] + rank of this slot among same-bin slots of the block (in slot order)
+// stable scatter: new slot = offset[bin][block] + rank of this slot among same-bin slots of the block (in slot order).
+// One wave per 64 slots (grid = blocks x kRebinBlock / 64): the same-bin slots of the block's EARLIER quarters are counted from
+// their keys (a coalesced 64-byte read per quarter), so the four quarters of a block move in parallel and nothing goes through LDS
+// (which a batch at two waves per SIMD leaves no room for: 8 x 19.7 KB of a CU's 160).
 __global__ __launch_bounds__(64) void rebin_move_kernel(const float* __restrict__ st, float* __restrict__ st2, int N, int n, int lo,
                                                         int words, const uint8_t* __restrict__ keys,
                                                         const int* __restrict__ offsets, const int* __restrict__ eid,
                                                         int* __restrict__ eid2, int* __restrict__ slotOf) {
-  __shared__ int nextLds[kBins];   // where the block's next slot of each bin goes
-  volatile int* next = nextLds;    // lanes read what another lane of the wave wrote a round earlier
-  const int lane = threadIdx.x;
-  if (lane < kBins) next[lane] = offsets[lane * gridDim.x + blockIdx.x];
-  __syncthreads();
-#pragma unroll 1
-  for (int q = 0; q < kRebinBlock / 64; ++q) {
-    const int slot = blockIdx.x * kRebinBlock + q * 64 + lane;
-    const int key = slot < n ? (int)keys[slot] : -1;
-    int dst = -1;
-    unsigned long long todo = __ballot(key >= 0);
-    while (todo) {   // one round per distinct key of these 64 slots (waves of a sorted batch hold one to three)
-      const int k = __shfl(key, __ffsll((long long)todo) - 1, 64);
-      const unsigned long long m = __ballot(key == k);
-      if (key == k) dst = next[k] + __popcll(m & ((1ull << lane) - 1ull));
-      __builtin_amdgcn_wave_barrier();            // every read of next[k] above is issued before the update below (one wave, in-order LDS)
-      if (lane == __ffsll((long long)m) - 1) next[k] += __popcll(m);
-      __builtin_amdgcn_wave_barrier();
-      todo &= ~m;
-    }
-    if (slot < n) {
-      for (int f = 0; f < words; ++f) st2[(size_t)f * N + dst] = st[(size_t)f * N + slot];
-      const int e = eid[slot];
-      eid2[dst] = e;
-      slotOf[e] = lo + dst;
-    }
+  constexpr int Q = kRebinBlock / 64;
+  const int lane = threadIdx.x, blk = blockIdx.x / Q, q = blockIdx.x % Q, nBlocks = gridDim.x / Q;
+  const int slot = blk * kRebinBlock + q * 64 + lane;
+  const int key = slot < n ? (int)keys[slot] : -1;
+  int prevKey[Q - 1];
+#pragma unroll
+  for (int p = 0; p < Q - 1; ++p) {
+    const int s2 = blk * kRebinBlock + p * 64 + lane;
+    prevKey[p] = (p < q && s2 < n) ? (int)keys[s2] : -2;
+  }
+  int dst = -1;
+  unsigned long long todo = __ballot(key >= 0);
+  while (todo) {   // one round per distinct key of these 64 slots (waves of a sorted batch hold one to three)
+    const int k = __shfl(key, __ffsll((long long)todo) - 1, 64);
+    const unsigned long long m = __ballot(key == k);
+    int before = 0;
+#pragma unroll
+    for (int p = 0; p < Q - 1; ++p) before += __popcll(__ballot(prevKey[p] == k));
+    if (key == k) dst = offsets[k * nBlocks + blk] + before + __popcll(m & ((1ull << lane) - 1ull));
+    todo &= ~m;
+  }
+  if (slot < n) {
+    for (int f = 0; f < words; ++f) st2[(size_t)f * N + dst] = st[(size_t)f * N + slot];
+    const int e = eid[slot];
+    eid2[dst] = e;
+    slotOf[e] = lo + dst;
   }
 }
 
@@ -775,7 +797,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   if (h->twoWidths && nEnvSteps > 0 && nPasses == 1 && stepBudget == 0 && h->waveBatch == 0 && lanes == 64 && !h->waveTimes &&
       (cohort >= 0 || h->nCohorts == 1) && h->sortedBlocks[cIdx] > 0) {
     const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;
-    heavyEnd = h->binOffsets + (size_t)cIdx * nBlocksAll * kBins + (size_t)(kBins - 1) * h->sortedBlocks[cIdx];   // start of the asleep bin
+    heavyEnd = h->binOffsets + (size_t)cIdx * binTableStride(nBlocksAll) + (size_t)(kBins - 1) * h->sortedBlocks[cIdx];   // start of the asleep bin
     grid = dim3(h->nSimds + 2 + (n + 63) / 64);   // heavy blocks <= max(nSimds, heavy / 64) + 1, light blocks <= light / 64 + 1
   }
   if (cohort < 0) {
@@ -829,13 +851,13 @@ static int launch_rebin(blcd_handle h, bool midChunk = false, int tEnd = 0) {
     const int lo = h->cohortLo[c], n = h->cohortLo[c + 1] - lo;
     hipStream_t stream = cohort_stream(h, c);
     const int nBlocks = (n + kRebinBlock - 1) / kRebinBlock;
-    int* counts = h->binCounts + (size_t)c * nBlocksAll * kBins;
-    int* offsets = h->binOffsets + (size_t)c * nBlocksAll * kBins;
+    int* counts = h->binCounts + (size_t)c * binTableStride(nBlocksAll);
+    int* offsets = h->binOffsets + (size_t)c * binTableStride(nBlocksAll);
     h->sortedBlocks[c] = midChunk ? 0 : nBlocks;
     hipLaunchKernelGGL(rebin_hist_kernel, dim3(nBlocks), dim3(64), 0, stream, h->dScene, h->st + lo, h->N, n, h->keys + lo, counts,
                        midChunk && h->rebinEvery <= 0 ? -1 : h->binMode, tEnd);
     hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(64), 0, stream, counts, offsets, nBlocks * kBins);
-    hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks), dim3(64), 0, stream, h->st + lo, h->st2 + lo, h->N, n, lo, (int)h->words,
+    hipLaunchKernelGGL(rebin_move_kernel, dim3(nBlocks * (kRebinBlock / 64)), dim3(64), 0, stream, h->st + lo, h->st2 + lo, h->N, n, lo, (int)h->words,
                        h->keys + lo, offsets, h->eid + lo, h->eid2 + lo, h->slotOf);
   }
   HIPCHK(hipGetLastError());
@@ -1068,8 +1090,8 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   HIPCHK(hipMalloc((void**)&h->keys, (size_t)n_envs));
   {
     int nBlocks = (n_envs + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;
-    HIPCHK(hipMalloc((void**)&h->binCounts, (size_t)blcd_handle_s::kMaxCohorts * nBlocks * kBins * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&h->binOffsets, (size_t)blcd_handle_s::kMaxCohorts * nBlocks * kBins * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->binCounts, (size_t)blcd_handle_s::kMaxCohorts * binTableStride(nBlocks) * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->binOffsets, (size_t)blcd_handle_s::kMaxCohorts * binTableStride(nBlocks) * sizeof(int)));
   }
   hipLaunchKernelGGL(iota_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, h->stream, h->eid, h->slotOf, n_envs);
   HIPCHK(hipGetLastError());
