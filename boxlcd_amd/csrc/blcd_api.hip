@@ -1159,6 +1159,8 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
   // 5 / 10 / 15 / 20 - its waves are so uneven (5 of 64 lanes busy on average) that regrouping them twice as often pays; the circles
   // two-body class and the three-body class show no trend (Bounce2-100k, Object3-100k within noise or best at 20) and keep 20.
   if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 2 && kCfgs[h->cfg].sh == 0) h->rolloutChunk = 10;
+  // the circles two-body class (round 4, on the cheaper re-bin kernels): Bounce2-100k 8.75 / 9.21 / 9.26 / 9.52 / 8.44e7 at 10 / 20 / 50 / 100 / 200
+  if (!h->chunkFixed && h->rebinEvery > 0 && h->hostScene.nb == 2 && kCfgs[h->cfg].sh == 1) h->rolloutChunk = 100;
   if (const char* ev = getenv("BLCD_COHORT_SWAP")) h->cohortSwap = atoi(ev) != 0;
   if (const char* ev = getenv("BLCD_CHUNK0")) {
     int a = 0, b = 0;
