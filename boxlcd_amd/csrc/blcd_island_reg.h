@@ -542,6 +542,7 @@ struct RegIsland {
   }
   template <bool TRACK = true>
   __device__ __forceinline__ bool sweepContact(int k, RContact& c_) {
+    if constexpr (NB == 1) return sweepContactT<true, TRACK>(k, c_);
     if (__ballot(c_.pA >= 4) == 0) return sweepContactT<true, TRACK>(k, c_);   // wave-uniform: every sweeping lane has a wall on side A
     return sweepContactT<false, TRACK>(k, c_);
   }
@@ -625,6 +626,7 @@ struct RegIsland {
   }
   template <bool TOI = false>
   __device__ __forceinline__ float positionContact(const RContact& c_, float minSeparation) {
+    if constexpr (NB == 1) return positionContactT<TOI, true>(c_, minSeparation);   // a one-body island: every contact is (wall, the body)
     if (__ballot(c_.pA >= 4) == 0) return positionContactT<TOI, true>(c_, minSeparation);
     return positionContactT<TOI, false>(c_, minSeparation);
   }
@@ -833,7 +835,10 @@ struct RegIsland {
 #ifndef BLCD_CYC_REF_LDS
 #define BLCD_CYC_REF_LDS 1
 #endif
-  static constexpr bool kCycRefLds = BLCD_CYC_REF_LDS && NB == 2;   // Brent's reference row in LDS (velocitySweeps); the three-body class loses 5 % with it (Object3-100k 2.44e7 -> 2.31e7)
+#ifndef BLCD_TOI1_REF_LDS
+#define BLCD_TOI1_REF_LDS 0   // the one-body TOI mini-island (Env::toiIslandReg) of a class keeps its reference row in LDS too (set per class by the build)
+#endif
+  static constexpr bool kCycRefLds = BLCD_CYC_REF_LDS && (NB == 2 || (NB == 1 && BLCD_TOI1_REF_LDS));   // Brent's reference row in LDS (velocitySweeps); the three-body class loses 5 % with it (Object3-100k 2.44e7 -> 2.31e7)
   static __device__ __forceinline__ float* cycRefLds() {
     __shared__ float blk[kCycRefLds ? kCycW * 64 : 1];
     return blk;

@@ -2103,25 +2103,47 @@ struct Env {
   // up to 20 TOI position iterations, velocity constraints initialised WITH restitution and without warm starting, the
   // velocity sweeps for the rest of the step (same bit-safe early exits as islandSolveReg), position integration.
   // Every contact of a TOI island here is (wall, b) - other dynamic bodies are skipped when it is built (no bullets).
+#ifndef BLCD_TOI_ONEBODY
+#define BLCD_TOI_ONEBODY 0
+#endif
+  // BLCD_TOI_ONEBODY (per class): the TOI mini-island is staged as what it is - ONE moving body and its wall contacts - on a
+  // one-body RegIsland (body b is its body 0, every contact is (wall, proxy 4)): no select chains over the class's NB bodies, the
+  // wall side folded out statically, cycle rows of 3 + 4 kRegC words instead of 3 NB + 4 kRegC.  Same arithmetic in the same order
+  // (the other bodies of the full-size island never moved: no contact of a TOI island names them).
+  static constexpr bool kToi1 = BLCD_TOI_ONEBODY && NB >= 2 && !SCHED;
+  using RegT = RegIsland<kToi1 ? 1 : NB, kToi1 ? 0 : NJ, kRegC, kToi1 ? false : kRegLds, kToi1 ? false : kRegCtLds>;
   __device__ __forceinline__ void toiIslandReg(int b, int nic, float h) {
-    RegI R;
-    R.L = regIslandLds();
-    R.C = regContactLds();
+    RegT R;
+    if constexpr (kToi1) {
+      R.L = nullptr;
+      R.C = nullptr;
+    } else {
+      R.L = regIslandLds();
+      R.C = regContactLds();
+    }
     R.nc = nic;
     R.nj = 0;
-    R.deadQ = deadQ;
+    const int b0 = kToi1 ? 0 : b;            // the moving body's index inside R
+    if constexpr (kToi1) {
+      R.deadQ = (deadQ & 0xfu) | (((deadQ >> (4 + b)) & 1u) << 4);
+      R.setPos(0, BodyPos{c[b], a[b]});
+      R.setVel(0, BodyVel{v[b], w[b]});
+      R.setMass(0, BodyMass{invMass[b], invI[b], lc[b]});
+    } else {
+      R.deadQ = deadQ;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      R.setPos(i, BodyPos{c[i], a[i]});
-      R.setVel(i, BodyVel{v[i], w[i]});
-      R.setMass(i, BodyMass{invMass[i], invI[i], lc[i]});
+      for (int i = 0; i < NB; ++i) {
+        R.setPos(i, BodyPos{c[i], a[i]});
+        R.setVel(i, BodyVel{v[i], w[i]});
+        R.setMass(i, BodyMass{invMass[i], invI[i], lc[i]});
+      }
     }
     Manifold mans[kRegC];
 #pragma unroll
     for (int k = 0; k < kRegC; ++k) {
       if (k < nic) {
         int s = ic.get(k);
-        RContact& c_ = R.ct[k];
+        auto& c_ = R.ct[k];
         const Manifold m = manGet(s);
         mans[k] = m;
         slotAB(s, &c_.pA, &c_.pB);
@@ -2138,6 +2160,7 @@ struct Env {
         c_.lp1 = m.points[1].localPoint;
         c_.radiusA = radiusOf(c_.pA);
         c_.radiusB = radiusOf(c_.pB);
+        if constexpr (kToi1) c_.pB = 4;    // side B of every contact of a TOI island is the moving body (side A a wall): body 0 of R
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           RPoint& p = c_.points[j];
@@ -2167,7 +2190,7 @@ struct Env {
 #ifdef BLCD_PROF_TOI2
     { unsigned long long qb_ = __builtin_amdgcn_s_memtime(); if (qrec_) prof[3] += qb_ - qa_; }
 #endif
-    const BodyPos pb0 = R.getPos(b);
+    const BodyPos pb0 = R.getPos(b0);
     c0[b] = pb0.c;                                   // "leap of faith to new safe state"
     a0[b] = pb0.a;
 #pragma unroll
@@ -2179,8 +2202,8 @@ struct Env {
 #else
     R.velocitySweeps(S->velIters, h);
 #endif
-    BodyPos pp = R.getPos(b);
-    BodyVel vv = R.getVel(b);
+    BodyPos pp = R.getPos(b0);
+    BodyVel vv = R.getVel(b0);
     {
       Vec2 translation = h * vv.v;
       if (Dot(translation, translation) > kMaxTranslationSquared) {
