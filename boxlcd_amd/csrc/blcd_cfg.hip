@@ -151,7 +151,13 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
             // 16x16 frames: 256 B = one dword per lane.  Writing each lane's own frame row by row makes every store touch 64
             // different cache lines; instead the lanes park their 16 row masks in LDS and the wave writes one whole frame per
             // store instruction (fully coalesced), frame k being the environment held by lane k.
+            // Round 4: the masks are parked [row][lane] (row stride 68) and every store instruction writes FOUR whole frames: lane l
+            // owns row l & 15 of frame 4 g + (l >> 4), expands its 16 mask bits to 16 bytes and stores them as one dwordx4 - 16
+            // LDS reads (conflict-free) and 16 stores of 1 KB per env-step instead of 64 + 64 of 256 B (LCD emission was 1.3 ms
+            // of a 9.3 ms Bounce-100k rollout, tools/emit_cost.py).
             const int lane = (int)threadIdx.x;
+            constexpr int RS = EnvT::kFrameRowStride;
+            uint32_t* const ldsE = ldsRows + 16 * RS;          // the wave's environment ids (rewritten every step: the block is shared with the solver in some classes)
             ok = true;
             if (reuse) {   // this lane's rows of the previous step are still in LDS (nothing else lives in that block for joint-free classes)
               if (valid) copyObsRow(obsOut, t, N, e, S->nobs);
@@ -159,20 +165,27 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
               uint32_t rows[16];
               ok = emit_env<16, uint32_t, float, SH == 1>(S, body, obsRowV, nullptr, rows);
 #pragma unroll
-              for (int y = 0; y < 16; ++y) ldsRows[lane * 17 + y] = rows[y];
+              for (int y = 0; y < 16; ++y) ldsRows[y * RS + lane] = rows[y];
             }
+            ldsE[lane] = (uint32_t)e;
             emitted = true;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             uint8_t* frames = lcdOut + (size_t)t * N * lcdRow;
-            const int row = lane >> 2, x0 = (lane & 3) * 4;   // this lane's 4 pixels of any frame
+            const int row = lane & 15, sub = lane >> 4;        // this lane's row of frame 4 g + sub
             const int nFrames = __popcll(__ballot(valid));      // shadow lanes are the wave's last lanes: their frames are not written
-            for (int k = 0; k < nFrames; ++k) {
-              const int ek = __builtin_amdgcn_readlane(e, k);
-              const uint32_t m = ldsRows[k * 17 + row];
-              const uint32_t px = ((((m >> x0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
-              *reinterpret_cast<uint32_t*>(frames + (size_t)ek * 256 + 4 * lane) = px;
+#pragma unroll 4
+            for (int g = 0; g < 16; ++g) {
+              const int k = 4 * g + sub;
+              const uint32_t m = ldsRows[row * RS + k];
+              const uint32_t ek = ldsE[k];
+              uint4 px;
+              px.x = ((((m >> 0) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+              px.y = ((((m >> 4) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+              px.z = ((((m >> 8) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+              px.w = ((((m >> 12) & 0xfu) * 0x00204081u) & 0x01010101u) ^ 0x01010101u;
+              if (k < nFrames) *reinterpret_cast<uint4*>(frames + (size_t)ek * 256 + 16 * row) = px;
             }
             __builtin_amdgcn_wave_barrier();
           } else if (valid) {

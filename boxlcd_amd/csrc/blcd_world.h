@@ -1806,16 +1806,20 @@ struct Env {
     }
   }
   static __device__ __forceinline__ float* ctLdsBase() {
-    __shared__ float blk[kRegCtLds ? RegI::kCtLdsWords : 64 * 17];
+    __shared__ float blk[kRegCtLds ? RegI::kCtLdsWords : kFrameLdsWords];
     return blk;
   }
   __device__ __forceinline__ float* regContactLds() {
     if constexpr (kRegCtLds) return ctLdsBase() + threadIdx.x;
     else return nullptr;
   }
-  // 64 x 17 words for step_kernel's wave-coalesced 16x16 frame stores
+  // step_kernel's wave-coalesced 16x16 frame stores: 16 rows x (64 + 4) row masks, [row][lane] (row stride 68: a lane's four
+  // consecutive frames are one aligned 16-byte read, and the 64 lanes of a store instruction - 16 rows x 4 frames - hit 64 different
+  // banks), then the wave's 64 environment ids
+  static constexpr int kFrameRowStride = 68;
+  static constexpr int kFrameLdsWords = 16 * kFrameRowStride + 64;
   static __device__ __forceinline__ uint32_t* ldsFrameRows() {
-    static_assert(!kRegCtLds || RegI::kCtLdsWords >= 64 * 17, "frame rows must fit the contact block");
+    static_assert(!kRegCtLds || RegI::kCtLdsWords >= kFrameLdsWords, "frame rows must fit the contact block");
     return reinterpret_cast<uint32_t*>(ctLdsBase());
   }
   // MODE 0: the whole island solve; 1: resumed inside the velocity sweeps (see islandSolve); 2: resumed inside the position
