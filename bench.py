@@ -357,33 +357,42 @@ def main():
     cfgs = {}
     for name, n_total, rolls in (('LuxoBall', 50000, 2), ('Object2', 200000, 3)):
       n_r = n_total // world                       # equal shards (all_gather_into_tensor); the remainder of an uneven cut is dropped and reported
-      ww = Workload(name, n_r, T, local, dev, seed=1000, env_id_base=rank * n_r)
-      ww.enable_gather(world, args.gather, rank)
-      sec = time_rollouts(ww, rolls, 1, bdist, torch)
-      sec2 = time_rollouts(ww, rolls, 0, bdist, torch, gather=False)
-      if rank == 0:
-        cfgs[f'{name}-{n_total}-sharded-x{world}'] = {
-            'value': rolls * T * n_r * world / sec, 'unit': 'env-steps/s', 'scaling': 'strong', 'envs_total': n_r * world, 'envs_per_gpu': n_r, 'rollouts': rolls,
-            'seconds': sec, 'gather': args.gather, 'stepping_only': {'value': rolls * T * n_r * world / sec2, 'unit': 'env-steps/s', 'seconds': sec2},
-            'wire': wire_model(world, n_r, T, ww.d, args.gather, sec2 / rolls, weak=False), 'faulted_envs': int((ww.h.faults() != 0).sum())}
-      ww.close()
-      del ww
+      try:                                         # an error that every rank hits alike (allocation, a Python slip) must not cost the main line
+        ww = Workload(name, n_r, T, local, dev, seed=1000, env_id_base=rank * n_r)
+        ww.enable_gather(world, args.gather, rank)
+        sec = time_rollouts(ww, rolls, 1, bdist, torch)
+        sec2 = time_rollouts(ww, rolls, 0, bdist, torch, gather=False)
+        if rank == 0:
+          cfgs[f'{name}-{n_total}-sharded-x{world}'] = {
+              'value': rolls * T * n_r * world / sec, 'unit': 'env-steps/s', 'scaling': 'strong', 'envs_total': n_r * world, 'envs_per_gpu': n_r, 'rollouts': rolls,
+              'seconds': sec, 'gather': args.gather, 'stepping_only': {'value': rolls * T * n_r * world / sec2, 'unit': 'env-steps/s', 'seconds': sec2},
+              'wire': wire_model(world, n_r, T, ww.d, args.gather, sec2 / rolls, weak=False), 'faulted_envs': int((ww.h.faults() != 0).sum())}
+        ww.close()
+        del ww
+      except Exception as ex:
+        cfgs[f'{name}-{n_total}-sharded-x{world}'] = {'error': repr(ex)}
       torch.cuda.empty_cache()
     if rank == 0:
       out['configs'] = cfgs
   if rank == 0 and world == 1 and not args.no_configs and args.env == 'Bounce':
     # policy-in-the-loop call shape (one env-step per call, device tensors): what PPO / SAC consumers see
-    out['step_loop'] = {'Bounce-100000': step_loop('Bounce', 100000, local, 200), 'Urchin-50000': step_loop('Urchin', 50000, local, 40)}
+    try:
+      out['step_loop'] = {'Bounce-100000': step_loop('Bounce', 100000, local, 200), 'Urchin-50000': step_loop('Urchin', 50000, local, 40)}
+    except Exception as ex:
+      out['step_loop'] = {'error': repr(ex)}
     # the other BASELINE workloads, driver-run on this one GPU: north_star's Dropbox-100k target, configs[2] Urchin-50k, and the
     # whole batches of configs[3] LuxoBall-50k and configs[4] Object2-200k (they fit one MI355X)
     cfgs = {}
     for name, n_envs, rolls in (('Dropbox', 100000, 20), ('Urchin', 50000, 3), ('LuxoBall', 50000, 2), ('Object2', 200000, 2), ('Crab', 20000, 1)):
-      ww = Workload(name, n_envs, T, local, dev, seed=1000)
-      sec = time_rollouts(ww, rolls, 0 if name == 'Crab' else 1, bdist, torch)     # the largest class: one cold rollout (seconds each)
-      cfgs[f'{name}-{n_envs}'] = {'value': rolls * T * n_envs / sec, 'unit': 'env-steps/s', 'rollouts': rolls, 'seconds': sec,
-                                  'faulted_envs': int((ww.h.faults() != 0).sum()), 'roofline': ww.roofline(rolls)}
-      ww.close()
-      del ww
+      try:
+        ww = Workload(name, n_envs, T, local, dev, seed=1000)
+        sec = time_rollouts(ww, rolls, 0 if name == 'Crab' else 1, bdist, torch)     # the largest class: one cold rollout (seconds each)
+        cfgs[f'{name}-{n_envs}'] = {'value': rolls * T * n_envs / sec, 'unit': 'env-steps/s', 'rollouts': rolls, 'seconds': sec,
+                                    'faulted_envs': int((ww.h.faults() != 0).sum()), 'roofline': ww.roofline(rolls)}
+        ww.close()
+        del ww
+      except Exception as ex:      # an extra workload must not cost the main line
+        cfgs[f'{name}-{n_envs}'] = {'error': repr(ex)}
       torch.cuda.empty_cache()
     out['configs'] = cfgs
   if rank == 0:
