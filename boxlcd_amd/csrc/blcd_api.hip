@@ -632,7 +632,8 @@ struct blcd_handle_s {
   int waveBatch = 0;
   // two wave widths per launch for re-binned batches (BLCD_TWO_WIDTHS=0 turns it off): the awake slots in narrower waves once they
   // no longer fill the SIMDs; sortedBlocks[c] = blocks of cohort c's last slot sort (0 = the current order is not a sorted one)
-  int twoWidths = 16, nSimds = 0;
+  int unsortedSpread = 1;   // BLCD_UNSORTED_SPREAD=0: ranges that no sort has ordered keep full waves
+  int twoWidths = 16, nSimds = 0, twSlots = 0;   // twSlots: wave slots the awake region of a two-width launch is spread over (BLCD_TW_SLOTS; default nSimds)
   int sortedBlocks[kMaxCohortsDecl] = {0, 0, 0, 0};
   // goal epilogue (blcd_goal_*): device-resident goals, previous deltas and scratch observation buffers
   blcd_goal_desc goal{};
@@ -786,19 +787,26 @@ static int pick_cfg(const DevScene& S) {
 static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int nWorldSteps, int setMotors,
                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, long long actStride = 0, uint8_t* lcdOut = nullptr,
                        float* obsOut = nullptr, int cohort = -1, int pass = 0, int nPasses = 1, int lcdBits = 0, int stepBudget = 0) {
-  const int lanes = h->lanes;
+  int lanes = h->lanes;
   const int lo = cohort < 0 ? 0 : h->cohortLo[cohort];
   const int n = cohort < 0 ? h->N : h->cohortLo[cohort + 1] - lo;
   hipStream_t stream = cohort < 0 ? h->stream : cohort_stream(h, cohort);
+  const bool widthsFree = h->twoWidths && nEnvSteps > 0 && nPasses == 1 && stepBudget == 0 && h->waveBatch == 0 && lanes == 64 && !h->waveTimes &&
+                          (cohort >= 0 || h->nCohorts == 1);
+  // a slot range that no sort has ordered yet (the first chunk after a full reset of a circles-only scene) and that is smaller
+  // than one full wave per wave slot: the same spreading as the awake region of a two-width launch, by the plain `lanes` argument
+  if (widthsFree && h->rebinEvery > 0 && h->sortedBlocks[cohort < 0 ? 0 : cohort] <= 0 && h->unsortedSpread && h->twSlots > 0 && (long long)n < 64LL * h->twSlots) {
+    const int l = (n + h->twSlots - 1) / h->twSlots;
+    lanes = l < h->twoWidths ? h->twoWidths : l;
+  }
   dim3 grid((n + lanes - 1) / lanes), block(kBlock);
   // two wave widths (see step_kernel): only for the plain kernel on a slot order that the last sort produced for exactly this range
   const int* heavyEnd = nullptr;
   const int cIdx = cohort < 0 ? 0 : cohort;
-  if (h->twoWidths && nEnvSteps > 0 && nPasses == 1 && stepBudget == 0 && h->waveBatch == 0 && lanes == 64 && !h->waveTimes &&
-      (cohort >= 0 || h->nCohorts == 1) && h->sortedBlocks[cIdx] > 0) {
+  if (widthsFree && h->sortedBlocks[cIdx] > 0) {
     const int nBlocksAll = (h->N + kRebinBlock - 1) / kRebinBlock + blcd_handle_s::kMaxCohorts;
     heavyEnd = h->binOffsets + (size_t)cIdx * binTableStride(nBlocksAll) + (size_t)(kBins - 1) * h->sortedBlocks[cIdx];   // start of the asleep bin
-    grid = dim3(h->nSimds + 2 + (n + 63) / 64);   // heavy blocks <= max(nSimds, heavy / 64) + 1, light blocks <= light / 64 + 1
+    grid = dim3(h->twSlots + 2 + (n + 63) / 64);   // heavy blocks <= max(nSimds, heavy / 64) + 1, light blocks <= light / 64 + 1
   }
   if (cohort < 0) {
     if (!e0) {
@@ -809,7 +817,7 @@ static int launch_step(blcd_handle h, const float* dActions, int nEnvSteps, int 
   }
   StepArgs A{h->dScene, h->st + lo, h->N, n, h->eid + lo, dActions, nEnvSteps, nWorldSteps, setMotors, lanes, h->waveTimes, actStride, lcdOut, obsOut, h->dFaultAny,
              pass, (pass + 1 < nPasses || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? h->yieldMaxLanes : 0, h->dSchedStats, lcdBits,
-             (nPasses > 1 || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? 1 : 0, stepBudget, heavyEnd, h->nSimds | (h->twoWidths << 16),
+             (nPasses > 1 || stepBudget > 0 || (h->waveBatch > 0 && nEnvSteps > 0)) ? 1 : 0, stepBudget, heavyEnd, (heavyEnd ? h->twSlots : h->nSimds) | (h->twoWidths << 16),
              stepBudget > 0 || nPasses > 1 ? 0 : h->waveBatch};
   int idx = 0;
 #define X(a, b, c, d) \
@@ -1113,10 +1121,25 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
     HIPCHK(hipGetDeviceProperties(&prop, device));
     const int simds = prop.multiProcessorCount * 4;
     h->nSimds = simds;
-    // narrowest wave of the awake region (0 = one width).  Measured (tools/tw_bench.sh): Object2-200k +6 %, Bounce2-100k +9 %,
-    // Object3-100k +12 % at 16; the one-body classes lose (Bounce-100k -4 %, Dropbox-100k -1 %: narrow waves give up the
-    // wave-coalesced frame store and the sharing of impact steps that the impact-time sort sets up) and keep one width
-    h->twoWidths = h->hostScene.nb >= 2 ? 16 : 0;
+    // narrowest wave of the awake region (0 = one width).  Round 3 (tools/tw_bench.sh): Object2-200k +6 %, Bounce2-100k +9 %,
+    // Object3-100k +12 % at 16, while the one-body classes lost (Bounce-100k -4 %, Dropbox-100k -1 %) because a narrow wave gave up
+    // the wave-coalesced frame store.  Round 4: the lanes beyond a narrow wave's width shadow its last environment (step_kernel), so
+    // every wave keeps that path, and the one-body classes gain twice: a cohort's 50 000 awake slots become 1 021 waves of 49 lanes -
+    // with two cohorts exactly two waves on every SIMD instead of 1 563 full waves spread 2 / 1 - and the awake eighth of a late
+    // chunk is spread over all SIMDs.  Bounce-100k 2.15e9 -> 2.31 / 2.34 / 2.31 / 2.31 / 2.25 / 2.22e9 at 4 / 6 / 8 / 12 / 16 / 32,
+    // Dropbox-100k 1.32e9 -> 1.39e9 (8, 16); Object3-100k 2.51e7 -> 2.73e7 (the shadow lanes alone, at 16; 2.78 at 8, 2.56 at 32);
+    // Bounce2-100k 9.57e7 / 9.82e7 / 1.05e8 at 8 / 16 / 32; Object2-200k 9.50 / 9.47 / 9.32e7 at 8 / 16 / 32.
+    // Spreading over 2 048 wave slots per cohort instead of 1 024 (BLCD_TW_SLOTS) loses everywhere (Bounce-100k 2.21e9, Object3-100k 2.24e7).
+    h->twoWidths = h->hostScene.nb == 1 ? 8 : (h->hostScene.nb == 2 && kCfgs[h->cfg].sh == 1 ? 32 : 16);
+    h->twSlots = simds;
+    if (const char* ev = getenv("BLCD_TW_SLOTS")) {
+      int q = atoi(ev);
+      if (q >= 64 && q <= 32768) h->twSlots = q;
+    }
+    // ... and the same spreading for a range no sort has ordered yet (launch_step): Bounce-100k 2.32e9 -> 2.37e9; the one-wave-per-SIMD
+    // classes lose (Bounce2-100k 1.04e8 -> 1.00e8: two cohorts of 1 021 waves are two rounds of waves either way) and keep full waves
+    h->unsortedSpread = h->hostScene.nb == 1;
+    if (const char* ev = getenv("BLCD_UNSORTED_SPREAD")) h->unsortedSpread = atoi(ev) != 0;
     if (const char* ev = getenv("BLCD_TWO_WIDTHS")) {
       int q = atoi(ev);
       h->twoWidths = q <= 0 ? 0 : (q == 1 ? 16 : (q > 64 ? 64 : q));

@@ -50,38 +50,47 @@ __global__ __launch_bounds__(kBlock, BLCD_WAVES_PER_EU) void step_kernel(const D
   // `lanes` (<= 64) environments per wave: the path is bound by per-wave serial latency and lane divergence, not by
   // VALU throughput, so partially filled waves (more, shorter waves) can finish a launch sooner.
   int slot;
-  bool valid = true;   // false: a shadow lane of the ragged last wave (computes, never stores)
+  bool valid = true;   // false: a shadow lane (computes what the wave's last environment computes, never stores)
+  // this wave holds the slots [first, first + width) below `end`
+  int first, width, end = nSlots;
   if (heavyEnd) {
     // Two wave widths in one launch (re-binned batches).  The slot sort puts the environments that are not asleep first
     // (*heavyEnd of them, heaviest first).  While they oversubscribe the SIMDs, full waves are best (total wave time counts); once
     // most of the batch sleeps, the launch lasts as long as ONE awake wave's dependent chain while most SIMDs idle - then the
     // awake environments are spread over all SIMDs in narrower waves, whose union of code paths (who hits a wall this step,
-    // who needs the TOI sub-step) is smaller.  Placement only.  The sleeping tail keeps full waves (coalesced frame stores).
+    // who needs the TOI sub-step) is smaller.  Placement only.  The sleeping tail keeps full waves.
     int he = *heavyEnd;
     he = he < 0 ? 0 : (he > nSlots ? nSlots : he);
     const int wmin = nSimds >> 16, ns = nSimds & 0xffff;   // narrowest width in the high half
     const int wh = he >= 64 * ns ? 64 : (he <= wmin * ns ? wmin : (he + ns - 1) / ns);
     const int heavyBlocks = (he + wh - 1) / wh;
     if ((int)blockIdx.x < heavyBlocks) {
-      if ((int)threadIdx.x >= wh) return;
-      slot = blockIdx.x * wh + threadIdx.x;
-      if (slot >= he) return;
+      first = blockIdx.x * wh;
+      width = wh;
+      end = he;
     } else {
-      slot = he + ((int)blockIdx.x - heavyBlocks) * 64 + threadIdx.x;
-      if (slot >= nSlots) return;
+      first = he + ((int)blockIdx.x - heavyBlocks) * 64;
+      width = 64;
     }
   } else {
-    if ((int)threadIdx.x >= lanes || (int)threadIdx.x >= Env<NB, NJ, NP, SH, SCHED>::kMaxLanes) return;   // the host never asks for more lanes than the class's LDS blocks hold
-    slot = blockIdx.x * lanes + threadIdx.x;   // state is stored in slot order; eid[slot] is the environment it holds
-    if (slot >= nSlots) {
-      // The ragged last wave of a 64-lane launch (100 000 environments = 1 562 waves + 32 lanes).  Its missing lanes used to
-      // exit here, which sent the wave down the per-lane emission path (a frame needs all 64 lanes to write it, see below): full
-      // raster + float64 observation glue on EVERY step, no reuse for environments at rest - one such wave was the whole
-      // 1.7 ms of a sleeping Dropbox chunk (0.47 ms without it; profiles/r04_dropbox100k_rest_timeline.txt).  Instead the
-      // missing lanes shadow the range's last environment: same inputs, same arithmetic, no store (`valid`), so every wave
-      // of the launch is a full one.  The scheduler's kernel and narrower waves keep the early exit.
-      if (SCHED || lanes != 64 || nSlots < 1) return;
-      slot = nSlots - 1;
+    first = blockIdx.x * lanes;   // state is stored in slot order; eid[slot] is the environment it holds
+    width = lanes;
+  }
+  if (first >= end) return;
+  slot = first + (int)threadIdx.x;
+  {
+    const int last = (first + width < end ? first + width : end) - 1;
+    if ((int)threadIdx.x >= width || slot > last) {
+      // Lanes without an environment of their own: the ragged last wave of a launch (100 000 environments = 1 562 waves + 32
+      // lanes) and every lane beyond the width of a narrow wave.  They used to exit here, which sent the wave down the per-lane
+      // emission path (a frame needs all 64 lanes to write it, see below): full raster + float64 observation glue on EVERY step,
+      // no reuse for environments at rest - one such wave was the whole 1.7 ms of a sleeping Dropbox chunk (0.47 ms without it;
+      // profiles/r04_dropbox100k_rest_timeline.txt), and the narrow waves of the two-width launches paid it on every step.
+      // Instead they shadow the wave's last environment: same inputs, same arithmetic (no extra code path for the wave), no
+      // store (`valid`), so every wave is a full one.  The scheduler's kernel keeps the early exit, and so do lanes for which
+      // the class has no LDS column (the host never asks for more lanes than the class's LDS blocks hold).
+      if (SCHED || (int)threadIdx.x >= Env<NB, NJ, NP, SH, SCHED>::kMaxLanes) return;
+      slot = last;
       valid = false;
     }
   }
