@@ -27,3 +27,5 @@ for rep in range(2):
     k = len(tot) // 8
     print('   mean wave ms by eighth of the block order:', [round(float(tot[i * k:(i + 1) * k].mean()), 3) for i in range(8)])
     print('   mean kcycles collide/solve/toi/toi-event', (wt[:, 1:5].mean(0) / 1e3).round(1), ' max-wave', (wt[np.argmax(tot), 1:5] / 1e3).round(1))
+    # 5 #toi calls (lane max) 6 #events (lane max) | 7 cycles inside the full TOI routine, 8 wave-level executions of it (wave sums)
+    print('   mean per wave: TOI calls (lane max) %.1f, events (lane max) %.1f, full-routine executions %.1f, kcycles inside them %.1f' % (wt[:, 5].mean(), wt[:, 6].mean(), wt[:, 8].mean(), wt[:, 7].mean() / 1e3))
