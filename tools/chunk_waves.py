@@ -29,3 +29,5 @@ for rep in range(2):
     print('   mean kcycles collide/solve/toi/toi-event', (wt[:, 1:5].mean(0) / 1e3).round(1), ' max-wave', (wt[np.argmax(tot), 1:5] / 1e3).round(1))
     # 5 #toi calls (lane max) 6 #events (lane max) | 7 cycles inside the full TOI routine, 8 wave-level executions of it (wave sums)
     print('   mean per wave: TOI calls (lane max) %.1f, events (lane max) %.1f, full-routine executions %.1f, kcycles inside them %.1f' % (wt[:, 5].mean(), wt[:, 6].mean(), wt[:, 8].mean(), wt[:, 7].mean() / 1e3))
+    if os.environ.get('CW_RAW'):   # diagnostic builds that give the eight slots other meanings (-DBLCD_PROF_TOI: 0 init 1 phase 1 2 all of SolveTOI 3 events 4 phase 2 5 event rounds' rest)
+      print('   raw slot means (k):', (wt[:, 1:9].mean(0) / 1e3).round(1))
