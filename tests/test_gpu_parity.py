@@ -356,16 +356,21 @@ def test_cohorts_of_an_oversubscribed_batch_change_nothing(monkeypatch):
       assert (a[3] == 0).all() and (b[3] == 0).all()
 
 
-@pytest.mark.parametrize('n', [10, 64, 65, 130, 255])
-def test_rebin_and_cohort_knobs_on_small_batches_change_nothing(monkeypatch, n):
+@pytest.mark.parametrize('name,n', [('Object2', 10), ('Object2', 64), ('Object2', 65), ('Object2', 130), ('Object2', 255),
+                                    ('Dropbox', 10), ('Dropbox', 130), ('Bounce', 65), ('Bounce', 1000)])
+def test_rebin_and_cohort_knobs_on_small_batches_change_nothing(monkeypatch, name, n):
   """BLCD_REBIN=1 / BLCD_COHORTS=4 are documented as placement-only knobs: on batches too small to give every cohort a whole wave
-  the handle falls back to fewer cohorts (never an empty or out-of-range slot range) and results equal the default run."""
+  the handle falls back to fewer cohorts (never an empty or out-of-range slot range) and results equal the default run.  On the
+  one-body scenes a forced re-bin also brings the narrow waves of the unsorted first chunk (8 lanes + 56 shadow lanes each) and of
+  the two-width launches to batches of a few waves."""
   T = 40
-  env, poses, sel = parity.make_batch('Object2', n, 3)
+  env, poses, sel = parity.make_batch(name, n, 3)
   d = env.scene.desc
   res = []
-  for knobs in ({}, {'BLCD_REBIN': '1'}, {'BLCD_REBIN': '1', 'BLCD_COHORTS': '4'}):
-    for k in ('BLCD_REBIN', 'BLCD_COHORTS'):
+  for knobs in ({}, {'BLCD_REBIN': '1'}, {'BLCD_REBIN': '1', 'BLCD_COHORTS': '4'}, {'BLCD_REBIN': '1', 'BLCD_LANES': '64', 'BLCD_CHUNK': '7', 'BLCD_TWO_WIDTHS': '5'},
+                {'BLCD_REBIN': '1', 'BLCD_LANES': '64', 'BLCD_UNSORTED_SPREAD': '0', 'BLCD_CHUNK': '10'}, {'BLCD_REBIN': '1', 'BLCD_LANES': '64'}):
+    # (BLCD_LANES=64: small batches otherwise run 16-lane waves, which switches the two-width paths off)
+    for k in ('BLCD_REBIN', 'BLCD_COHORTS', 'BLCD_CHUNK', 'BLCD_TWO_WIDTHS', 'BLCD_UNSORTED_SPREAD', 'BLCD_LANES'):
       monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
       monkeypatch.setenv(k, v)
@@ -485,8 +490,9 @@ def test_two_wave_widths_change_nothing(monkeypatch, name, n):
   env, poses, sel = parity.make_batch(name, n, 13)
   d = env.scene.desc
   res = []
-  for tw in ('0', '16'):
+  for tw in ('0', '16', '8', '5'):   # 5: widths that are not a divisor of anything
     monkeypatch.setenv('BLCD_TWO_WIDTHS', tw)
+    monkeypatch.setenv('BLCD_UNSORTED_SPREAD', '0' if tw == '16' else '1')
     h = Handle(d, n, 0)
     h.reset(None, poses, sel)
     lcd = np.zeros((T, n, d.lcd_h, d.lcd_w), np.uint8)
@@ -496,9 +502,10 @@ def test_two_wave_widths_change_nothing(monkeypatch, name, n):
     res.append((lcd, obs, [x.copy() for x in h.debug_dump()]))
     assert not h.faults().any()
     h.close()
-  assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
-  for x, y in zip(res[0][2], res[1][2]):
-    assert (x == y).all()
+  for b in res[1:]:
+    assert (res[0][0] == b[0]).all() and (res[0][1] == b[1]).all()
+    for x, y in zip(res[0][2], b[2]):
+      assert (x == y).all()
 
 
 def _random_convex(rng, k, r0, r1):
