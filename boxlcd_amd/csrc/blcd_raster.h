@@ -5,9 +5,10 @@
 // (`ImagingDrawPolygon` / `polygon_generic` / `hline8`, `ImagingDrawEllipse`) as characterised in SURVEY.md App. C:
 // int truncation of the float64 pixel coordinates, float32 edge interpolation, half-open RU/RD rounding, lower-end
 // duplication; variant 0 is the rule of the Pillow the reference pins (9.0.1: horizontal-edge spans + span merging),
-// variant 1 adds Pillow >= 12's sub-pixel corner joining, variant 2 is the Pillow 8.2-8.4 rule the reference's published
-// demo GIFs were recorded with (horizontal edges skipped, plain pairing, crossed span ends swapped): they differ only on
-// thin links that truncate to degenerate polygons.  Drawing order is irrelevant in mode '1' (every body clears bits).
+// variant 1 adds Pillow >= 12's sub-pixel corner joining, variant 2 is the rule the reference's published demo GIFs were
+// recorded with (each pixel once from a scan position that starts at 0, horizontal edges drawn from that position only,
+// crossed span ends swapped: the behaviour of the Pillow 9.0.x the reference pins): they differ only on thin links that
+// truncate to degenerate polygons.  Drawing order is irrelevant in mode '1' (every body clears bits).
 #pragma once
 #include "blcd_collide.h"
 #include "blcd_ellipse_lut.h"
@@ -117,10 +118,37 @@ struct Raster {
         xx[t + 1] = key;
       }
       if (variant == 2) {
+        // each pixel once, from a scan position that starts at 0; this row's horizontal edges are drawn from that position, and one
+        // that begins to the right of it is skipped (the one-pixel-high polygons of the recordings: DESIGN.md 2.1)
+        int x_pos = 0;
+        auto horizontalLines = [&]() {
+          for (int k = 0; k < n; k++) {
+            if (e[k].ymin != y || e[k].ymin != e[k].ymax) continue;
+            int xmin = e[k].xmin;
+            if (x_pos < xmin) continue;
+            const int xmax = e[k].xmax;
+            if (x_pos > xmin) {
+              xmin = x_pos;
+              if (xmax < xmin) continue;
+            }
+            hline(xmin, y, xmax);
+            x_pos = xmax + 1;
+          }
+        };
         for (int i = 1; i < j; i += 2) {
-          int a = RoundUp(xx[i - 1]), b = RoundDown(xx[i]);
-          hline(a < b ? a : b, y, a < b ? b : a);
+          const int x_end = RoundDown(xx[i]);
+          if (x_end < x_pos) continue;
+          horizontalLines();
+          if (x_end < x_pos) continue;
+          int x_start = RoundUp(xx[i - 1]);
+          if (x_pos > x_start) {
+            x_start = x_pos;
+            if (x_end < x_start) continue;
+          }
+          hline(x_start < x_end ? x_start : x_end, y, x_start < x_end ? x_end : x_start);   // crossed ends are swapped
+          x_pos = x_end + 1;
         }
+        horizontalLines();
         continue;
       }
       int x_pos = 0;

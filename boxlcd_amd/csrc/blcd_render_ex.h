@@ -91,11 +91,36 @@ __device__ inline void rexPolygonFillRow(const RowCanvas& cv, const int* xy, int
     while (t >= 0 && xx[t] > key) { xx[t + 1] = xx[t]; --t; }
     xx[t + 1] = key;
   }
-  if (variant == 2) {
+  if (variant == 2) {   // as Raster::polygon (blcd_raster.h): scan position from 0, horizontal edges from that position only
+    int x_pos = 0;
+    auto horizontalLines = [&]() {
+      for (int k = 0; k < n; ++k) {
+        if (e[k].ymin != y || e[k].ymin != e[k].ymax) continue;
+        int xmin = e[k].xmin;
+        if (x_pos < xmin) continue;
+        const int xmax = e[k].xmax;
+        if (x_pos > xmin) {
+          xmin = x_pos;
+          if (xmax < xmin) continue;
+        }
+        cv.span(xmin, xmax, ink);
+        x_pos = xmax + 1;
+      }
+    };
     for (int i = 1; i < j; i += 2) {
-      const int a = rexRoundUp(xx[i - 1]), b = rexRoundDown(xx[i]);
-      cv.span(a < b ? a : b, a < b ? b : a, ink);
+      const int x_end = rexRoundDown(xx[i]);
+      if (x_end < x_pos) continue;
+      horizontalLines();
+      if (x_end < x_pos) continue;
+      int x_start = rexRoundUp(xx[i - 1]);
+      if (x_pos > x_start) {
+        x_start = x_pos;
+        if (x_end < x_start) continue;
+      }
+      cv.span(x_start < x_end ? x_start : x_end, x_start < x_end ? x_end : x_start, ink);
+      x_pos = x_end + 1;
     }
+    horizontalLines();
     return;
   }
   int x_pos = 0;

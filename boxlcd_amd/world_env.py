@@ -87,8 +87,9 @@ class _EnvSpec:
     if raster_variant is None:
       # Polygon scan-conversion rule (Pillow changed it between releases; they differ only on sub-pixel-thin links):
       #   2 = the Pillow that rendered the reference's published recordings - pinned frame for frame by eight of them,
-      #       incl. 150 frames of thin-limbed UrchinBall (DEFAULT: the only variant with evidence from the reference itself)
-      #   1 = Pillow 12.2 (pinned by tests/golden/pillow_*.npz)      0 = inferred Pillow 9.0.x rule (no fixture of its own)
+      #       incl. 150 frames of thin-limbed UrchinBall and the one-pixel-high polygons of the Luxo recordings (DEFAULT: the
+      #       only variant with evidence from the reference itself; by its behaviour the 9.0.x line the reference pins)
+      #   1 = Pillow 12.2 (pinned by tests/golden/pillow_*.npz)      0 = variant 1 without corner joining (no fixture of its own)
       raster_variant = int(os.environ.get('BOXLCD_RASTER_VARIANT', '2'))
     self.raster_variant = raster_variant
     self.world_def = fill_robots(world_def, self.G)

@@ -5,8 +5,8 @@
 // FLIP_TOP_BOTTOM).  Pillow (`Pillow==9.0.1`, requirements.txt:19) is un-vendored; the scan-conversion rules are
 // the behavioural spec of SURVEY.md App. C (probed against Pillow 12.2.0):
 //   variant 1 "modern"  = Pillow 12.2.0 (with sub-pixel corner joining)      -> pinned by tests/golden/pillow_*.npz
-//   variant 0 "legacy"  = the same scan rule without corner joining (the Pillow 9.0.x the reference pins)
-//   variant 2 "recording era" = Pillow 8.2-8.4, what the reference's published GIFs were rendered with (see below)
+//   variant 0 "legacy"  = variant 1's scan rule without corner joining (no fixture of its own)
+//   variant 2 "recording era" = what the reference's published GIFs were rendered with (Pillow 9.0.x by its behaviour, see below)
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -117,12 +117,15 @@ static inline void add_edge(Edge* e, int x0, int y0, int x1, int y1) {
 }
 static inline float edge_x(const Edge* e, int y) { return (y - e->y0) * e->dx + e->x0; }
 
-// Variant 2, "recording era": the polygon fill of the Pillow 8.2-8.4 releases that were current when the reference's demo
-// GIFs were recorded (2021; the repository pinned Pillow 9.0.1 later).  Relative to variant 0: horizontal edges are
-// skipped instead of drawn, crossings are paired without span merging, and a span whose rounded ends cross (x0 > x1,
-// two coincident crossings at k+0.5) is drawn with its ends swapped, as that era's hline did.
-// Only used by tests/test_oracle_physics.py to compare against the robot GIFs (thin links truncate to degenerate
-// polygons there, which later releases draw differently); the product implements variants 0 and 1 only.
+// Variant 2, "recording era" = the polygon fill the reference's demo GIFs were rendered with, and by every sign the release the
+// reference pins (requirements.txt: Pillow==9.0.1): the first release that draws each polygon pixel once (a scan position per row;
+// horizontal edges are not drawn up front but from that position) and the last before the one-pixel-high-polygon fix - a horizontal
+// edge that begins to the right of the scan position is skipped, and the position starts at 0.  Evidence (tools/degenerate_polys.py,
+// profiles/r04_param_sweep.md): of the eleven robot links of the exactly replayed recording frames that truncate to a single row, the
+// recordings draw exactly the two whose row begins at x = 0 (Luxo frame 37, LuxoBall frame 38) and none of the other nine; this
+// rule reproduces all eleven and changes no other pixel of the 1 126 recorded frames.  Relative to variant 0 also: a span whose
+// rounded ends cross (two coincident crossings at k + 0.5) is drawn with its ends swapped, as that era's hline did.
+// The product implements the same rule (blcd_raster.h, blcd_render_ex.h) and uses it by default.
 static inline void hline_swapping(Canvas& im, int x0, int y0, int x1) {
   if (x0 > x1) std::swap(x0, x1);
   hline(im, x0, y0, x1);
@@ -183,7 +186,37 @@ static inline void draw_polygon(Canvas& im, const int* xy, int count, int varian
     }
     std::sort(xx, xx + j);
     if (variant == 2) {
-      for (int i = 1; i < j; i += 2) hline_swapping(im, RoundUp(xx[i - 1]), y, RoundDown(xx[i]));
+      // "only draw each polygon pixel once" with the scan position starting at 0, and the horizontal edges of this row drawn from
+      // that position: one that begins to the right of it is "after the current position" and is skipped
+      int x_pos = 0;
+      auto horizontal_lines = [&]() {
+        for (int k = 0; k < n; k++) {
+          if (e[k].ymin != y || e[k].ymin != e[k].ymax) continue;
+          int xmin = e[k].xmin;
+          if (x_pos < xmin) continue;
+          const int xmax = e[k].xmax;
+          if (x_pos > xmin) {
+            xmin = x_pos;
+            if (xmax < xmin) continue;
+          }
+          hline(im, xmin, y, xmax);
+          x_pos = xmax + 1;
+        }
+      };
+      for (int i = 1; i < j; i += 2) {
+        const int x_end = RoundDown(xx[i]);
+        if (x_end < x_pos) continue;
+        horizontal_lines();
+        if (x_end < x_pos) continue;
+        int x_start = RoundUp(xx[i - 1]);
+        if (x_pos > x_start) {
+          x_start = x_pos;
+          if (x_end < x_start) continue;
+        }
+        hline_swapping(im, x_start, y, x_end);
+        x_pos = x_end + 1;
+      }
+      horizontal_lines();
       continue;
     }
     int x_pos = 0;
