@@ -160,6 +160,23 @@ class Handle:
     except Exception:
       pass
 
+  _ext = None
+
+  def _after_torch(self, *xs):
+    """Order the call behind torch.  The library launches on its OWN (non-blocking) stream; a CUDA tensor handed to a call was produced -
+    and an output buffer may still be read - by work queued on torch's current stream (`step_torch(policy(obs))`: the policy's kernels
+    have been launched, not finished).  So the handle's stream first waits, on the device, for torch's current stream (an event +
+    hipStreamWaitEvent, no host synchronisation).  The other direction needs nothing: every call returns after synchronising its stream."""
+    for x in xs:
+      if x is not None and getattr(x, 'is_cuda', False):
+        import torch
+        if self._ext is None:
+          self._ext = (torch.cuda.ExternalStream(int(self.stream()), device=x.device), torch.cuda.Event())
+        ext, ev = self._ext
+        ev.record(torch.cuda.current_stream(x.device))   # one cached event: each record supersedes the last
+        ext.wait_event(ev)
+        return
+
   def pair_table(self):
     t = np.zeros((self.n_pairs, 2), np.int32)
     _check(self.lib.blcd_pair_table(self._h, _ptr(t)))
@@ -174,6 +191,7 @@ class Handle:
       assert poses.shape == (n, self.nb, 3), poses.shape
     if shape_sel is not None and not hasattr(shape_sel, 'data_ptr'):
       shape_sel = np.ascontiguousarray(shape_sel, dtype=np.int32)
+    self._after_torch(poses, shape_sel)
     _check(self.lib.blcd_reset(self._h, _ptr(idxs), n, _ptr(poses), _ptr(shape_sel)))
 
   def set_poses(self, idxs, poses, mask=None):
@@ -190,6 +208,7 @@ class Handle:
     if actions is not None and not hasattr(actions, 'data_ptr'):
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (self.n, self.n_act), actions.shape
+    self._after_torch(actions)
     _check(self.lib.blcd_step(self._h, _ptr(actions), int(n_steps)))
 
   def step_obs(self, actions, fs, lcd):
@@ -197,6 +216,7 @@ class Handle:
     if actions is not None and not hasattr(actions, 'data_ptr'):
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (self.n, self.n_act), actions.shape
+    self._after_torch(actions, fs, lcd)
     _check(self.lib.blcd_step_obs(self._h, _ptr(actions), _ptr(fs), _ptr(lcd)))
 
   def reset_sampled(self, idxs, seed, ops):
@@ -205,6 +225,7 @@ class Handle:
     if idxs is not None and not hasattr(idxs, 'data_ptr'):
       idxs = np.ascontiguousarray(idxs, dtype=np.int32)
     arr = (SampleOp * len(ops))(*ops)
+    self._after_torch(idxs)
     _check(self.lib.blcd_reset_sampled(self._h, _ptr(idxs), n, C.c_uint64(int(seed)), arr, len(ops)))
 
   def sample_reseed(self):
@@ -217,6 +238,7 @@ class Handle:
   def shape_sel(self, out=None):
     """int32 [n, nb]: the shape every body currently has ('random' objects choose one per reset)"""
     out = np.zeros((self.n, self.nb), np.int32) if out is None else out
+    self._after_torch(out)
     _check(self.lib.blcd_get_shape_sel(self._h, _ptr(out)))
     return out
 
@@ -224,6 +246,7 @@ class Handle:
     if actions is not None and not hasattr(actions, 'data_ptr'):
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (T, self.n, self.n_act), actions.shape
+    self._after_torch(actions, lcd_out, obs_out)
     _check(self.lib.blcd_rollout(self._h, _ptr(actions), int(T), _ptr(lcd_out), _ptr(obs_out)))
 
   def rollout_bits(self, actions, T, lcd_bits_out=None, obs_out=None):
@@ -231,6 +254,7 @@ class Handle:
     if actions is not None and not hasattr(actions, 'data_ptr'):
       actions = np.ascontiguousarray(actions, dtype=np.float32)
       assert actions.shape == (T, self.n, self.n_act), actions.shape
+    self._after_torch(actions, lcd_bits_out, obs_out)
     _check(self.lib.blcd_rollout_bits(self._h, _ptr(actions), int(T), _ptr(lcd_bits_out), _ptr(obs_out)))
 
   def goal_set(self, mode, idxs_cols, thresh, rew_scale, diff_delt, goal_full_state, goal_lcd=None, env_idxs=None):
@@ -246,6 +270,7 @@ class Handle:
     n = self.n if env_idxs is None else len(env_idxs)
     if env_idxs is not None:
       env_idxs = np.ascontiguousarray(env_idxs, dtype=np.int32)
+    self._after_torch(goal_full_state, goal_lcd)
     _check(self.lib.blcd_goal_set(self._h, C.byref(g), _ptr(env_idxs), n, _ptr(goal_full_state), _ptr(goal_lcd)))
 
   def goal_seed(self, env_idxs=None):
@@ -259,6 +284,7 @@ class Handle:
     rew = np.zeros(self.n, np.float64) if rew is None else rew
     done = np.zeros(self.n, np.uint8) if done is None else done
     delta = np.zeros(self.n, np.float64) if delta is None else delta
+    self._after_torch(rew, done, delta)
     _check(self.lib.blcd_goal_eval(self._h, _ptr(rew), _ptr(done), _ptr(delta)))
     return rew, done, delta
 
@@ -272,6 +298,7 @@ class Handle:
 
   def get_obs_into(self, fs, lcd):
     """device (torch) or host buffers, float32 obs."""
+    self._after_torch(fs, lcd)
     _check(self.lib.blcd_get_obs(self._h, _ptr(fs), 0, _ptr(lcd)))
 
   def render_poses(self, poses, shape_sel=None):

@@ -250,7 +250,13 @@ int blcd_set_state(blcd_handle h, const void* blob, size_t size);
  * 1 non-finite state, 2 circle larger than the ellipse table, 4 more simultaneous contacts than the scene class holds. */
 int blcd_get_faults(blcd_handle h, int32_t* flags);
 
-/* Blocks until the handle's stream is idle; blcd_stream returns the hipStream_t so torch can order work against it. */
+/* Blocks until the handle's stream is idle; blcd_stream returns the hipStream_t so that a caller can order work against it.
+ * Ordering contract for DEVICE buffers: the library launches on its own non-blocking stream and every entry point returns after
+ * synchronising that stream, so results are complete on return.  The other direction is the caller's: a device buffer handed to a
+ * call must be complete - and an output buffer no longer in use - on the caller's side, either by synchronising the producing stream
+ * or, without a host synchronisation, by making blcd_stream(h) wait for it (hipEventRecord on the producer's stream +
+ * hipStreamWaitEvent(blcd_stream(h), event)) before the call.  The shipped Python layer does the latter for torch tensors
+ * (boxlcd_amd/_lib.py Handle._after_torch; tests/test_gpu_api.py::test_device_tensors_are_ordered_behind_torchs_stream). */
 int blcd_sync(blcd_handle h);
 void* blcd_stream(blcd_handle h);
 

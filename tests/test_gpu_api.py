@@ -200,6 +200,34 @@ def test_device_resident_vector_env():
   a.close(); b.close()
 
 
+def test_device_tensors_are_ordered_behind_torchs_stream():
+  """`step_torch(policy(obs))`: when the call is made the policy's kernels have been LAUNCHED on torch's stream, not finished, and the
+  library steps on its own non-blocking stream - so the handle's stream must first wait for torch's (boxlcd_amd/_lib.py
+  Handle._after_torch).  Here the action tensor is the end of a long matmul chain and holds zeros until that chain has run; a step that
+  does not wait reads the zeros."""
+  import torch
+  n = 4096
+  a = B.BatchedWorldEnv('Urchin', n, seed=3)
+  b = B.BatchedWorldEnv('Urchin', n, seed=3)
+  a.reset_torch(); b.reset_torch()
+  big = torch.randn(3072, 3072, device='cuda')
+  acts = torch.zeros((n, a.act_size), device='cuda')
+  for t in range(4):
+    want = torch.empty_like(acts).uniform_(-1, 1)
+    torch.cuda.synchronize()
+    x = big
+    for _ in range(30):
+      x = (x @ big) * 1e-3                            # tens of milliseconds of queued work
+    acts.copy_(want + 0.0 * x[:1, :1].nan_to_num())   # the actions exist only once the chain has run
+    oa, *_ = a.step_torch(acts)                       # called while the chain is still running
+    fa = oa['full_state'].clone()
+    torch.cuda.synchronize()
+    acts.zero_()
+    ob, *_ = b.step_torch(want)
+    assert (fa == ob['full_state']).all(), t
+  a.close(); b.close()
+
+
 @pytest.mark.parametrize('name,n', [('Bounce', 70_000), ('Dropbox', 1000), ('Object2', 333), ('Urchin', 100), ('Crab', 40)])
 def test_step_obs_equals_step_then_get_obs(name, n):
   """blcd_step_obs (one call, one synchronisation: the step kernel writes the observation row and the frame itself) against
