@@ -23,6 +23,7 @@ SYMBOLS = {
     'blcd_set_poses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_step_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'blcd_step_obs_async': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'blcd_reset_sampled': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_int32]),
     'blcd_sample_reseed': (C.c_int, [C.c_void_p]),
     'blcd_sample_set_base': (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -218,6 +219,17 @@ class Handle:
       assert actions.shape == (self.n, self.n_act), actions.shape
     self._after_torch(actions, fs, lcd)
     _check(self.lib.blcd_step_obs(self._h, _ptr(actions), _ptr(fs), _ptr(lcd)))
+
+  def step_obs_async(self, actions, fs, lcd):
+    """blcd_step_obs_async: the same step queued on the handle's stream, no host synchronisation; CUDA tensors only.  The handle's stream
+    waits for torch's current stream before the step and torch's current stream waits for the handle's after it, so torch work queued
+    behind this call sees the outputs (`.cpu()` / `.item()` / `torch.cuda.synchronize()` wait for the step like for any torch kernel)."""
+    import torch
+    assert all(x is None or x.is_cuda for x in (actions, fs, lcd))
+    self._after_torch(actions, fs, lcd)
+    _check(self.lib.blcd_step_obs_async(self._h, _ptr(actions), _ptr(fs), _ptr(lcd)))
+    ext, ev = self._ext
+    torch.cuda.current_stream(ext.device).wait_stream(ext)
 
   def reset_sampled(self, idxs, seed, ops):
     """blcd_reset_sampled: reset environments idxs (None = all) from the device-side counter-based sampler"""

@@ -632,6 +632,7 @@ struct blcd_handle_s {
   int waveBatch = 0;
   // two wave widths per launch for re-binned batches (BLCD_TWO_WIDTHS=0 turns it off): the awake slots in narrower waves once they
   // no longer fill the SIMDs; sortedBlocks[c] = blocks of cohort c's last slot sort (0 = the current order is not a sorted one)
+  bool asyncPending = false;   // blcd_step_obs_async queued work that no call has synchronised yet
   int unsortedSpread = 1;   // BLCD_UNSORTED_SPREAD=0: ranges that no sort has ordered keep full waves
   int twoWidths = 16, nSimds = 0, twSlots = 0;   // twSlots: wave slots the awake region of a two-width launch is spread over (BLCD_TW_SLOTS; default nSimds)
   int sortedBlocks[kMaxCohortsDecl] = {0, 0, 0, 0};
@@ -889,7 +890,14 @@ static int rebin_if_due(blcd_handle h, int chunkNow = 0) {
   if (h->phase0Chunk > 0 && h->phase0NoSort && h->stepsSinceFullReset > 0 && h->stepsSinceFullReset < h->phase0Steps) return BLCD_OK;
   int interval = chunkNow > 0 ? chunkNow : (h->rolloutChunk > 0 ? h->rolloutChunk : 20);
   if (interval < h->rebinEvery) interval = h->rebinEvery;
-  if (h->stepsSinceRebin >= interval) return launch_rebin(h);
+  if (h->stepsSinceRebin >= interval) {
+    // an asynchronous step (blcd_step_obs_async) may still be running on the handle's stream, and the sort runs on the cohorts'
+    if (h->asyncPending) {
+      HIPCHK(hipStreamSynchronize(h->stream));
+      h->asyncPending = false;
+    }
+    return launch_rebin(h);
+  }
   return BLCD_OK;
 }
 
@@ -1533,8 +1541,30 @@ int blcd_step_obs(blcd_handle h, const float* actions, float* full_state, uint8_
   if (full_state && dObs != full_state) HIPCHK(hipMemcpyAsync(full_state, dObs, obsBytes, hipMemcpyDeviceToHost, h->stream));
   if (lcd && dLcd != lcd) HIPCHK(hipMemcpyAsync(lcd, dLcd, lcdBytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->asyncPending = false;
   HIPCHK(hipEventElapsedTime(&h->lastMs, h->ev0, h->ev1));
   return fault_status(h);
+}
+
+int blcd_step_obs_async(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_step_obs_async: bad handle");
+  HIPCHK(hipSetDevice(h->device));
+  for (const void* p : {(const void*)actions, (const void*)full_state, (const void*)lcd})
+    if (p && !is_device_ptr(p)) return fail(BLCD_ERR_INVALID, "blcd_step_obs_async: device buffers only (host buffers need the synchronising blcd_step_obs)");
+  h->lastLaunches = 0;
+  int rc;
+  if ((rc = rebin_if_due(h))) return rc;
+  if ((rc = join_cohort_stream(h))) return rc;
+  const bool fused = (h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0 && (full_state || lcd);
+  if (fused) {
+    if ((rc = launch_step(h, actions, 1, 0, 0, nullptr, nullptr, (long long)h->N * h->hostScene.nact, lcd, full_state))) return rc;
+  } else {
+    if ((rc = launch_step(h, actions, 1, 0, 0))) return rc;
+    if ((full_state || lcd) && (rc = launch_obs<float>(h, full_state, lcd))) return rc;
+  }
+  h->stepsSinceRebin += 1;
+  h->asyncPending = true;
+  return BLCD_OK;   // queued on blcd_stream(h); a fault this step raises is reported by the next synchronising call
 }
 
 static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out, int lcdBits);
@@ -1550,6 +1580,10 @@ int blcd_rollout_bits(blcd_handle h, const float* actions, int32_t T, uint8_t* l
 static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out, int lcdBits) {
   if (!h || T < 1) return fail(BLCD_ERR_INVALID, "blcd_rollout: bad arguments");
   HIPCHK(hipSetDevice(h->device));
+  if (h->asyncPending) {   // the cohorts' streams are not ordered behind an asynchronous step that is still queued on the handle's
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->asyncPending = false;
+  }
   const int nact = h->hostScene.nact, nobs = h->hostScene.nobs;
   const size_t lcdStep = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW / (lcdBits ? 8 : 1);
   const size_t obsStep = (size_t)h->N * nobs;
@@ -1996,6 +2030,7 @@ int blcd_sync(blcd_handle h) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_sync: bad handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->asyncPending = false;
   return BLCD_OK;
 }
 void* blcd_stream(blcd_handle h) { return h ? (void*)h->stream : nullptr; }

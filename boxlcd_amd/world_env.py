@@ -550,14 +550,19 @@ class BatchedWorldEnv(_EnvSpec):
     tb['ep_t'][torch.as_tensor(ii.astype(np.int64), device=tb['ep_t'].device)] = 0
     return self._obs_torch()
 
-  def step_torch(self, actions):
+  def step_torch(self, actions, sync=True):
     """step(actions) on CUDA tensors: actions f32 [N, act] on the device -> (obs dict of tensors, rew f64 [N] zeros,
     done bool [N], timeout bool [N]) - ONE call (blcd_step_obs: the step kernel writes the observation row and the frame itself),
-    one stream synchronisation, nothing crosses PCIe."""
+    one stream synchronisation, nothing crosses PCIe.
+    sync=False: no host synchronisation at all (blcd_step_obs_async) - the step is ordered between the torch work before and after it
+    on the device, the call returns while it runs; device faults are then only seen through `faults()`."""
     tb = self._torch_bufs()
     a = actions.contiguous() if actions.dtype == tb['full_state'].dtype else actions.float().contiguous()
     assert a.is_cuda and tuple(a.shape) == (self.num_envs, self.act_size)
-    self._step_handle(a, tb['full_state'], tb['lcd'])          # blcd_step_obs; a faulted environment does not abort the batch: see faults()
+    if sync:
+      self._step_handle(a, tb['full_state'], tb['lcd'])        # blcd_step_obs; a faulted environment does not abort the batch: see faults()
+    else:
+      self._handle().step_obs_async(a, tb['full_state'], tb['lcd'])
     tb['ep_t'] += 1
     self.ep_t += 1
     done = tb['ep_t'] >= int(self.G.ep_len)

@@ -165,6 +165,13 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps);
  * async_vector_env.py:191-242 returns the observations with the step).  full_state float32 [n_envs][n_obs], lcd uint8
  * [n_envs][lcd_h][lcd_w]; either may be NULL; host|device.  Same results as the two calls (tests/test_gpu_api.py). */
 int blcd_step_obs(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd);
+/* The same step WITHOUT the synchronisation, for consumers that stay on the device (a policy network between two steps): device
+ * buffers only; the call returns when the work is queued on blcd_stream(h).  Ordering in both directions is the caller's - make
+ * blcd_stream(h) wait for the producer of `actions` before the call and the consumer of the outputs wait for blcd_stream(h) after it
+ * (hipEventRecord + hipStreamWaitEvent; the Python layer does both for torch: BatchedWorldEnv.step_torch(sync=False)).  A fault
+ * raised by the step is not reported here: it stays readable through blcd_get_faults and is returned by the next synchronising
+ * step / rollout call. */
+int blcd_step_obs_async(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd);
 
 /* Fused rollout, replaces the inner loop of research/data.py:56-61 (`for j in range(ep_len): venv.step(act)`):
  * T env-steps with per-step actions [T][n_envs][n_act]; per-step outputs (any may be NULL):

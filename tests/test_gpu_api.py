@@ -228,6 +228,36 @@ def test_device_tensors_are_ordered_behind_torchs_stream():
   a.close(); b.close()
 
 
+@pytest.mark.parametrize('name,n,T', [('Bounce', 70_000, 130), ('Urchin', 300, 40), ('Object2', 66_000, 25)])
+def test_asynchronous_step_loop_equals_the_synchronous_one(name, n, T):
+  """step_torch(sync=False) = blcd_step_obs_async: no host synchronisation anywhere in the loop - the step is ordered on the device
+  between the torch kernels that produce its actions and those that consume its outputs.  A 'policy' that reads the previous
+  observation (so outputs feed inputs) drives an asynchronous env and a synchronous twin: same observations at every step, same
+  final state, across a re-bin boundary of the oversubscribed batches (Bounce: every 100 steps)."""
+  import torch
+  a = B.BatchedWorldEnv(name, n, seed=21)
+  b = B.BatchedWorldEnv(name, n, seed=21)
+  oa, ob = a.reset_torch(), b.reset_torch()
+  W = torch.randn(a.obs_size, max(1, a.act_size), device='cuda')
+  policy = lambda o: torch.tanh(o['full_state'].nan_to_num() @ W)[:, :a.act_size].contiguous()
+  snaps = []
+  for t in range(T):
+    oa, _, _, _ = a.step_torch(policy(oa), sync=False)
+    snaps.append((oa['full_state'].clone(), oa['lcd'].clone()))           # queued behind the step on torch's stream
+  for t in range(T):
+    ob, _, _, _ = b.step_torch(policy(ob))
+    assert (snaps[t][0] == ob['full_state']).all() and (snaps[t][1] == ob['lcd']).all(), t
+  assert not a.faults().any()
+  da, db = a._handle().debug_dump(), b._handle().debug_dump()
+  for x, y in zip(da, db):
+    assert (x == y).all()
+  # the synchronous entry points keep working on a handle that has asynchronous work behind it
+  oa, _, _, _ = a.step_torch(policy(oa))
+  ob, _, _, _ = b.step_torch(policy(ob))
+  assert (oa['full_state'] == ob['full_state']).all()
+  a.close(); b.close()
+
+
 @pytest.mark.parametrize('name,n', [('Bounce', 70_000), ('Dropbox', 1000), ('Object2', 333), ('Urchin', 100), ('Crab', 40)])
 def test_step_obs_equals_step_then_get_obs(name, n):
   """blcd_step_obs (one call, one synchronisation: the step kernel writes the observation row and the frame itself) against
