@@ -632,6 +632,7 @@ struct blcd_handle_s {
   int waveBatch = 0;
   // two wave widths per launch for re-binned batches (BLCD_TWO_WIDTHS=0 turns it off): the awake slots in narrower waves once they
   // no longer fill the SIMDs; sortedBlocks[c] = blocks of cohort c's last slot sort (0 = the current order is not a sorted one)
+  bool cohortsBusy = false;    // work has been queued on a cohort's own stream since the last join_cohort_stream
   bool asyncPending = false;   // blcd_step_obs_async queued work that no call has synchronised yet
   int unsortedSpread = 1;   // BLCD_UNSORTED_SPREAD=0: ranges that no sort has ordered keep full waves
   int twoWidths = 16, nSimds = 0, twSlots = 0;   // twSlots: wave slots the awake region of a two-width launch is spread over (BLCD_TW_SLOTS; default nSimds)
@@ -689,6 +690,7 @@ struct blcd_handle_s {
 
 static inline hipStream_t cohort_stream(blcd_handle h, int c) {
   if (h->cohortSwap && h->nCohorts >= 2 && c <= 1) c = 1 - c;
+  if (c > 0) h->cohortsBusy = true;   // every user of a cohort's own stream queues work on it
   return c > 0 ? h->cstream[c] : h->stream;
 }
 
@@ -877,7 +879,9 @@ static int launch_rebin(blcd_handle h, bool midChunk = false, int tEnd = 0) {
 }
 // everything outside the fused rollout runs on the handle's stream: let it see cohort 1's re-bin
 static int join_cohort_stream(blcd_handle h) {
+  if (!h->cohortsBusy) return BLCD_OK;   // nothing has been queued on them since the last join (a step loop pays this check per call)
   for (int c = 1; c < h->nCohorts; ++c) HIPCHK(hipStreamSynchronize(h->cstream[c]));
+  h->cohortsBusy = false;
   return BLCD_OK;
 }
 // Re-bin lazily, right before a launch, once a chunk's worth of env steps has passed since the last sort - whoever cut the
@@ -1710,6 +1714,7 @@ static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t*
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int c = 1; c < h->nCohorts; ++c) HIPCHK(hipStreamSynchronize(h->cstream[c]));
+  h->cohortsBusy = false;
   float total = 0.0f;  // step-kernel time only: each event pair brackets one step_kernel launch on this stream
   if (cohortTimed) {   // cohorts: the whole overlapped sequence (both cohorts' launches and their re-bins), start to join
     HIPCHK(hipEventElapsedTime(&total, h->evPool[0], h->evPool[1]));

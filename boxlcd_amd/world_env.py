@@ -338,6 +338,11 @@ class BatchedWorldEnv(_EnvSpec):
     # environments would have sampled (tests/test_gpu_api.py::test_shards_with_one_seed_are_one_batch).
     self.env_id_base = int(env_id_base)
     self.ep_t = np.zeros(self.num_envs, np.int64)
+    # Episode clocks of the device-resident loop (step_torch): while every environment is at the same step of its episode (after a full
+    # reset, until a partial one) `done` is a cached constant tensor and neither clock costs a kernel or an O(N) host pass per step:
+    # _ep_same = that common step count (None once the clocks differ), _ep_lag = step_torch increments not yet added to the host array
+    self._ep_same = 0
+    self._ep_lag = 0
     self.seed(seed)
 
   def seed(self, seed=0):
@@ -458,8 +463,22 @@ class BatchedWorldEnv(_EnvSpec):
     """reset environments ii (int32 numpy) from the device sampler.  Reset counts and shape choices live on the device only
     (the render calls read the shapes back with blcd_get_shape_sel; snapshots carry the counts)."""
     h = self._handle()
-    h.reset_sampled(None if len(ii) == self.num_envs and (ii == np.arange(self.num_envs)).all() else ii, self._seed, self.sample_program())
+    full = len(ii) == self.num_envs and (ii == np.arange(self.num_envs)).all()
+    h.reset_sampled(None if full else ii, self._seed, self.sample_program())
+    self._flush_ep()
     self.ep_t[ii] = 0
+    if full:
+      self._ep_same = 0
+    elif self._ep_same is not None and self._ep_same != 0:
+      tb = getattr(self, '_tb', None)
+      if tb is not None:
+        tb['ep_t'].fill_(self._ep_same)      # the device clocks become per-environment from here on (reset_torch zeroes the reset ones)
+      self._ep_same = None
+
+  def _flush_ep(self):
+    if self._ep_lag:
+      self.ep_t += self._ep_lag
+      self._ep_lag = 0
 
   def sample_actions(self, T=None):
     shape = (self.num_envs, self.act_size) if T is None else (T, self.num_envs, self.act_size)
@@ -508,7 +527,14 @@ class BatchedWorldEnv(_EnvSpec):
     fs = np.zeros((self.num_envs, self.obs_size), np.float32)
     lcd = np.zeros((self.num_envs, d.lcd_h, d.lcd_w), np.uint8)
     self._step_handle(a, fs, lcd)
+    self._flush_ep()
     self.ep_t += 1
+    if self._ep_same is not None:
+      self._ep_same += 1
+    else:
+      tb = getattr(self, '_tb', None)
+      if tb is not None:
+        tb['ep_t'] += 1
     done = self.ep_t >= self.G.ep_len
     infos = [{'timeout': bool(d_)} for d_ in done]
     if self._any_fault:
@@ -529,14 +555,20 @@ class BatchedWorldEnv(_EnvSpec):
                   'lcd': torch.empty((self.num_envs, d.lcd_h, d.lcd_w), dtype=torch.uint8, device=dev),
                   'ep_t': torch.zeros(self.num_envs, dtype=torch.int64, device=dev),
                   'rew': torch.zeros(self.num_envs, dtype=torch.float64, device=dev),
-                  'pidx': torch.as_tensor(np.asarray(self.pobs_idxs, np.int64), device=dev)}
+                  'pidx': torch.as_tensor(np.asarray(self.pobs_idxs, np.int64), device=dev),
+                  'all_true': torch.ones(self.num_envs, dtype=torch.bool, device=dev),
+                  'all_false': torch.zeros(self.num_envs, dtype=torch.bool, device=dev),
+                  'proprio0': torch.zeros((self.num_envs, 1), dtype=torch.float32, device=dev)}
+      if self._ep_same is None:
+        self._flush_ep()
+        self._tb['ep_t'].copy_(torch.as_tensor(self.ep_t, device=dev))
     return self._tb
 
   def _obs_torch(self):
     tb = self._torch_bufs()
     self._handle().get_obs_into(tb['full_state'], tb['lcd'])
     fs = tb['full_state']
-    proprio = fs[:, tb['pidx']] if self.pobs_size != 0 else fs.new_zeros((self.num_envs, 1))
+    proprio = fs[:, tb['pidx']] if self.pobs_size != 0 else tb['proprio0']
     return {'full_state': fs, 'proprio': proprio, 'lcd': tb['lcd']}
 
   def reset_torch(self, idxs=None):
@@ -547,7 +579,8 @@ class BatchedWorldEnv(_EnvSpec):
     h = self._handle()
     ii = np.arange(self.num_envs, dtype=np.int32) if idxs is None else np.asarray(torch.as_tensor(idxs).cpu() if hasattr(idxs, 'cpu') else idxs, dtype=np.int32)
     self._reset_on_device(ii)          # sampled on the device: no pose ever crosses PCIe
-    tb['ep_t'][torch.as_tensor(ii.astype(np.int64), device=tb['ep_t'].device)] = 0
+    if self._ep_same is None:
+      tb['ep_t'][torch.as_tensor(ii.astype(np.int64), device=tb['ep_t'].device)] = 0
     return self._obs_torch()
 
   def step_torch(self, actions, sync=True):
@@ -563,11 +596,15 @@ class BatchedWorldEnv(_EnvSpec):
       self._step_handle(a, tb['full_state'], tb['lcd'])        # blcd_step_obs; a faulted environment does not abort the batch: see faults()
     else:
       self._handle().step_obs_async(a, tb['full_state'], tb['lcd'])
-    tb['ep_t'] += 1
-    self.ep_t += 1
-    done = tb['ep_t'] >= int(self.G.ep_len)
+    self._ep_lag += 1                  # the host clocks are brought up to date when something reads them (_flush_ep)
+    if self._ep_same is not None:      # every environment at the same step of its episode: a constant, no kernel
+      self._ep_same += 1
+      done = tb['all_true'] if self._ep_same >= int(self.G.ep_len) else tb['all_false']
+    else:
+      tb['ep_t'] += 1
+      done = tb['ep_t'] >= int(self.G.ep_len)
     fs = tb['full_state']
-    proprio = fs[:, tb['pidx']] if self.pobs_size != 0 else fs.new_zeros((self.num_envs, 1))
+    proprio = fs[:, tb['pidx']] if self.pobs_size != 0 else tb['proprio0']
     return {'full_state': fs, 'proprio': proprio, 'lcd': tb['lcd']}, tb['rew'], done, done
 
   def lcd_render(self, width=None, height=None, lcd_mode='1'):
