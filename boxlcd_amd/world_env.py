@@ -467,13 +467,16 @@ class BatchedWorldEnv(_EnvSpec):
     h.reset_sampled(None if full else ii, self._seed, self.sample_program())
     self._flush_ep()
     self.ep_t[ii] = 0
+    tb = getattr(self, '_tb', None)
     if full:
       self._ep_same = 0
     elif self._ep_same is not None and self._ep_same != 0:
-      tb = getattr(self, '_tb', None)
       if tb is not None:
-        tb['ep_t'].fill_(self._ep_same)      # the device clocks become per-environment from here on (reset_torch zeroes the reset ones)
+        tb['ep_t'].fill_(self._ep_same)      # the device clocks become per-environment from here on
       self._ep_same = None
+    if self._ep_same is None and tb is not None:
+      import torch
+      tb['ep_t'][torch.as_tensor(np.asarray(ii, np.int64), device=tb['ep_t'].device)] = 0
 
   def _flush_ep(self):
     if self._ep_lag:
@@ -578,9 +581,7 @@ class BatchedWorldEnv(_EnvSpec):
     tb = self._torch_bufs()
     h = self._handle()
     ii = np.arange(self.num_envs, dtype=np.int32) if idxs is None else np.asarray(torch.as_tensor(idxs).cpu() if hasattr(idxs, 'cpu') else idxs, dtype=np.int32)
-    self._reset_on_device(ii)          # sampled on the device: no pose ever crosses PCIe
-    if self._ep_same is None:
-      tb['ep_t'][torch.as_tensor(ii.astype(np.int64), device=tb['ep_t'].device)] = 0
+    self._reset_on_device(ii)          # sampled on the device: no pose ever crosses PCIe (and the episode clocks of ii restart)
     return self._obs_torch()
 
   def step_torch(self, actions, sync=True):

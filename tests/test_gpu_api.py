@@ -228,6 +228,45 @@ def test_device_tensors_are_ordered_behind_torchs_stream():
   a.close(); b.close()
 
 
+def test_episode_clocks_of_the_device_loop():
+  """step_torch keeps the episode clocks lazily (a constant `done` tensor while every environment shares a clock, per-environment
+  clocks after a partial reset, the host array brought up to date on demand): the `done` flags of a mixed sequence of torch steps,
+  numpy steps, partial and full resets equal those of a twin driven through the numpy API alone."""
+  import torch
+  n, L = 100, 6
+  a = B.BatchedWorldEnv('Dropbox', n, {'ep_len': L}, seed=5)
+  b = B.BatchedWorldEnv('Dropbox', n, {'ep_len': L}, seed=5)
+  a.reset_torch(); b.reset()
+  z = np.zeros((n, a.act_size), np.float32)
+  zt = torch.zeros((n, a.act_size), device='cuda')
+  rs = np.random.RandomState(0)
+  script = ['t', 't', 'p', 't', 'n', 't', 'T', 'P', 'T', 't', 't', 'f', 't', 'T', 'n', 't', 't', 'p', 't', 'P', 't', 't', 't', 't', 'F', 't', 't']
+  for k, op in enumerate(script):
+    if op in 'tTn':
+      if op == 'n':
+        _, _, da, _ = a.step(z)
+      else:
+        _, _, da, _ = a.step_torch(zt, sync=(op == 't'))
+        da = da.cpu().numpy()
+      _, _, db, _ = b.step(z)
+      assert (np.asarray(da) == db).all(), (k, op)
+      assert (a.ep_t + a._ep_lag == b.ep_t).all(), (k, op)
+    elif op in 'pP':
+      idx = np.sort(rs.choice(n, 17, replace=False))
+      if op == 'p':
+        a.reset_torch(torch.as_tensor(idx))
+      else:
+        a.reset(idx)                                  # a partial reset through the numpy API restarts the device clocks too
+      b.reset(idx)
+    else:
+      if op == 'f':
+        a.reset_torch()
+      else:
+        a.reset()
+      b.reset()
+  a.close(); b.close()
+
+
 @pytest.mark.parametrize('name,n,T', [('Bounce', 70_000, 130), ('Urchin', 300, 40), ('Object2', 66_000, 25)])
 def test_asynchronous_step_loop_equals_the_synchronous_one(name, n, T):
   """step_torch(sync=False) = blcd_step_obs_async: no host synchronisation anywhere in the loop - the step is ordered on the device
