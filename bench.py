@@ -229,11 +229,22 @@ def step_loop(env_name, N, local, steps, warmup=5):
     obs, rew, done, _ = env.step_torch(a.uniform_(-1, 1), sync=False)
   torch.cuda.synchronize()
   sec_async = time.perf_counter() - t0
+  # ... and with the step queued on torch's own stream (blcd_set_async_stream): no hand-off between streams either
+  for _ in range(warmup):
+    env.step_torch(a.uniform_(-1, 1), sync='inline')
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    obs, rew, done, _ = env.step_torch(a.uniform_(-1, 1), sync='inline')
+  torch.cuda.synchronize()
+  sec_inline = time.perf_counter() - t0
   faults = int((env.faults() != 0).sum())
   env.close()
   return {'value': steps * N / sec, 'unit': 'env-steps/s', 'env_steps_per_call': 1, 'calls': steps, 'ms_per_call': sec / steps * 1e3,
           'async': {'value': steps * N / sec_async, 'ms_per_call': sec_async / steps * 1e3, 'faults': faults,
                     'note': 'step_torch(sync=False) = blcd_step_obs_async: no host synchronisation, stream-ordered against torch in both directions'},
+          'inline': {'value': steps * N / sec_inline, 'ms_per_call': sec_inline / steps * 1e3,
+                     'note': "step_torch(sync='inline'): the asynchronous step queued ON torch's current stream (blcd_set_async_stream)"},
           'note': 'BatchedWorldEnv.step_torch = blcd_step_obs: one call, one launch (step_kernel writes the observation row and the frame), one stream '
                   'synchronisation, device tensors in and out (ordered behind torch\'s stream); round 3 issued blcd_step + blcd_get_obs (two launches, four synchronisations)'}
 

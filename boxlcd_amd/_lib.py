@@ -24,6 +24,7 @@ SYMBOLS = {
     'blcd_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_step_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'blcd_step_obs_async': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'blcd_set_async_stream': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'blcd_reset_sampled': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_int32]),
     'blcd_sample_reseed': (C.c_int, [C.c_void_p]),
     'blcd_sample_set_base': (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -220,12 +221,25 @@ class Handle:
     self._after_torch(actions, fs, lcd)
     _check(self.lib.blcd_step_obs(self._h, _ptr(actions), _ptr(fs), _ptr(lcd)))
 
-  def step_obs_async(self, actions, fs, lcd):
+  _async_stream = None
+
+  def step_obs_async(self, actions, fs, lcd, inline=False):
     """blcd_step_obs_async: the same step queued on the handle's stream, no host synchronisation; CUDA tensors only.  The handle's stream
     waits for torch's current stream before the step and torch's current stream waits for the handle's after it, so torch work queued
     behind this call sees the outputs (`.cpu()` / `.item()` / `torch.cuda.synchronize()` wait for the step like for any torch kernel)."""
     import torch
     assert all(x is None or x.is_cuda for x in (actions, fs, lcd))
+    if inline:
+      # the step is queued ON torch's current stream (blcd_set_async_stream): ordered like any torch kernel, no hand-off between streams
+      cur = int(torch.cuda.current_stream(actions.device).cuda_stream)   # 0 = the device's default stream (torch's, unless told otherwise)
+      if self._async_stream != cur:
+        _check(self.lib.blcd_set_async_stream(self._h, C.c_void_p(cur), 1))
+        self._async_stream = cur
+      _check(self.lib.blcd_step_obs_async(self._h, _ptr(actions), _ptr(fs), _ptr(lcd)))
+      return
+    if self._async_stream is not None:
+      _check(self.lib.blcd_set_async_stream(self._h, None, 0))
+      self._async_stream = None
     self._after_torch(actions, fs, lcd)
     _check(self.lib.blcd_step_obs_async(self._h, _ptr(actions), _ptr(fs), _ptr(lcd)))
     ext, ev = self._ext

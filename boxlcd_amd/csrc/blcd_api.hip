@@ -633,7 +633,13 @@ struct blcd_handle_s {
   // two wave widths per launch for re-binned batches (BLCD_TWO_WIDTHS=0 turns it off): the awake slots in narrower waves once they
   // no longer fill the SIMDs; sortedBlocks[c] = blocks of cohort c's last slot sort (0 = the current order is not a sorted one)
   bool cohortsBusy = false;    // work has been queued on a cohort's own stream since the last join_cohort_stream
-  bool asyncPending = false;   // blcd_step_obs_async queued work that no call has synchronised yet
+  // Asynchronous steps (blcd_step_obs_async): the stream holding queued work that no call has synchronised yet (nullptr: none) - the
+  // handle's own stream, or the caller's stream adopted with blcd_set_async_stream; evExt orders one behind the other on the device
+  bool pending = false;               // pendingStream holds queued asynchronous work (the stream itself may be the null stream)
+  hipStream_t pendingStream = nullptr;
+  bool asyncAdopt = false;            // blcd_set_async_stream: asynchronous steps go on asyncStream (which may be the null stream)
+  hipStream_t asyncStream = nullptr;
+  hipEvent_t evExt = nullptr;
   int unsortedSpread = 1;   // BLCD_UNSORTED_SPREAD=0: ranges that no sort has ordered keep full waves
   int twoWidths = 16, nSimds = 0, twSlots = 0;   // twSlots: wave slots the awake region of a two-width launch is spread over (BLCD_TW_SLOTS; default nSimds)
   int sortedBlocks[kMaxCohortsDecl] = {0, 0, 0, 0};
@@ -877,6 +883,25 @@ static int launch_rebin(blcd_handle h, bool midChunk = false, int tEnd = 0) {
   if (!midChunk || h->rebinEvery > 0) h->stepsSinceRebin = 0;
   return BLCD_OK;
 }
+// host-side wait for asynchronous steps that are still queued (on whichever stream they were put)
+static int drain_async(blcd_handle h) {
+  if (h->pending) {
+    HIPCHK(hipStreamSynchronize(h->pendingStream));
+    h->pending = false;
+  }
+  return BLCD_OK;
+}
+// every entry point that works on the handle's own stream: asynchronous steps queued on an adopted stream come first (device-side)
+static int enter(blcd_handle h) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->pending && h->pendingStream != h->stream) {
+    if (!h->evExt) HIPCHK(hipEventCreateWithFlags(&h->evExt, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->evExt, h->pendingStream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->evExt, 0));
+    h->pendingStream = h->stream;   // what is pending now sits behind that wait on the handle's own stream
+  }
+  return BLCD_OK;
+}
 // everything outside the fused rollout runs on the handle's stream: let it see cohort 1's re-bin
 static int join_cohort_stream(blcd_handle h) {
   if (!h->cohortsBusy) return BLCD_OK;   // nothing has been queued on them since the last join (a step loop pays this check per call)
@@ -896,10 +921,7 @@ static int rebin_if_due(blcd_handle h, int chunkNow = 0) {
   if (interval < h->rebinEvery) interval = h->rebinEvery;
   if (h->stepsSinceRebin >= interval) {
     // an asynchronous step (blcd_step_obs_async) may still be running on the handle's stream, and the sort runs on the cohorts'
-    if (h->asyncPending) {
-      HIPCHK(hipStreamSynchronize(h->stream));
-      h->asyncPending = false;
-    }
+    if (int rc = drain_async(h)) return rc;
     return launch_rebin(h);
   }
   return BLCD_OK;
@@ -1265,6 +1287,8 @@ int blcd_create(const blcd_scene_desc* scene, int32_t n_envs, int32_t device, bl
 int blcd_destroy(blcd_handle h) {
   if (!h) return BLCD_OK;
   (void)hipSetDevice(h->device);
+  if (h->pending) (void)hipStreamSynchronize(h->pendingStream);   // asynchronous steps still queued (possibly on the caller's stream)
+  if (h->evExt) (void)hipEventDestroy(h->evExt);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (int k = 0; k < 4; ++k)
     if (h->stage[k]) (void)hipFree(h->stage[k]);
@@ -1329,7 +1353,7 @@ static int check_idxs(blcd_handle h, const int32_t* idxs, int n, const char* who
 int blcd_reset(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const int32_t* shape_sel) {
   if (!h || !poses || n < 1) return fail(BLCD_ERR_INVALID, "blcd_reset: bad arguments");
   if (!idxs && n != h->N) return fail(BLCD_ERR_INVALID, "blcd_reset: idxs == NULL requires n == n_envs");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   if (int rcI = check_idxs(h, idxs, n, "blcd_reset")) return rcI;
   const int nb = h->hostScene.nb;
   const void *dIdx, *dPoses, *dSel;
@@ -1440,7 +1464,7 @@ int blcd_sample_set_base(blcd_handle h, uint64_t env_id_base) {
 
 int blcd_sample_reseed(blcd_handle h) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_sample_reseed: bad handle");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   if (h->dEpisode) HIPCHK(hipMemsetAsync(h->dEpisode, 0, (size_t)h->N * sizeof(int), h->stream));
   return BLCD_OK;
 }
@@ -1456,7 +1480,7 @@ int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t s
         (op.kind == 5 && (op.parent < 0 || op.parent >= nb || op.a >= nb)))
       return fail(BLCD_ERR_INVALID, "blcd_reset_sampled: malformed sampling program");
   }
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   int rc;
   if ((rc = check_idxs(h, idxs, n, "blcd_reset_sampled"))) return rc;
   if ((rc = sampler_buffers(h))) return rc;
@@ -1479,7 +1503,7 @@ int blcd_reset_sampled(blcd_handle h, const int32_t* idxs, int32_t n, uint64_t s
 int blcd_set_poses(blcd_handle h, const int32_t* idxs, int32_t n, const float* poses, const uint8_t* mask) {
   if (!h || !poses || n < 1) return fail(BLCD_ERR_INVALID, "blcd_set_poses: bad arguments");
   if (!idxs && n != h->N) return fail(BLCD_ERR_INVALID, "blcd_set_poses: idxs == NULL requires n == n_envs");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   if (int rcI = check_idxs(h, idxs, n, "blcd_set_poses")) return rcI;
   const int nb = h->hostScene.nb;
   const void *dIdx, *dPoses, *dMask;
@@ -1504,7 +1528,7 @@ static int fault_status(blcd_handle h) {
 int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
   if (!h || n_steps < 0) return fail(BLCD_ERR_INVALID, "blcd_step: bad arguments");
   if (n_steps == 0) return BLCD_OK;
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const void* dAct;
   int rc;
   if ((rc = in_ptr(h, 0, actions, (size_t)h->N * h->hostScene.nact * sizeof(float), &dAct))) return rc;
@@ -1522,7 +1546,7 @@ int blcd_step(blcd_handle h, const float* actions, int32_t n_steps) {
 // (research/rl/ppo.py:127-133 `o, r, d, _ = env.step(a)`; async_vector_env.py:191-242 returns the observations with the step).
 int blcd_step_obs(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_step_obs: bad handle");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const size_t obsBytes = (size_t)h->N * h->hostScene.nobs * sizeof(float), lcdBytes = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW;
   const void* dAct;
   void *dObs, *dLcd;
@@ -1545,9 +1569,18 @@ int blcd_step_obs(blcd_handle h, const float* actions, float* full_state, uint8_
   if (full_state && dObs != full_state) HIPCHK(hipMemcpyAsync(full_state, dObs, obsBytes, hipMemcpyDeviceToHost, h->stream));
   if (lcd && dLcd != lcd) HIPCHK(hipMemcpyAsync(lcd, dLcd, lcdBytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->asyncPending = false;
+  h->pending = false;
   HIPCHK(hipEventElapsedTime(&h->lastMs, h->ev0, h->ev1));
   return fault_status(h);
+}
+
+int blcd_set_async_stream(blcd_handle h, void* stream, int32_t adopt) {
+  if (!h) return fail(BLCD_ERR_INVALID, "blcd_set_async_stream: bad handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = drain_async(h)) return rc;
+  h->asyncAdopt = adopt != 0;
+  h->asyncStream = adopt ? (hipStream_t)stream : nullptr;
+  return BLCD_OK;
 }
 
 int blcd_step_obs_async(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd) {
@@ -1555,20 +1588,35 @@ int blcd_step_obs_async(blcd_handle h, const float* actions, float* full_state, 
   HIPCHK(hipSetDevice(h->device));
   for (const void* p : {(const void*)actions, (const void*)full_state, (const void*)lcd})
     if (p && !is_device_ptr(p)) return fail(BLCD_ERR_INVALID, "blcd_step_obs_async: device buffers only (host buffers need the synchronising blcd_step_obs)");
-  h->lastLaunches = 0;
-  int rc;
-  if ((rc = rebin_if_due(h))) return rc;
-  if ((rc = join_cohort_stream(h))) return rc;
-  const bool fused = (h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0 && (full_state || lcd);
-  if (fused) {
-    if ((rc = launch_step(h, actions, 1, 0, 0, nullptr, nullptr, (long long)h->N * h->hostScene.nact, lcd, full_state))) return rc;
-  } else {
-    if ((rc = launch_step(h, actions, 1, 0, 0))) return rc;
-    if ((full_state || lcd) && (rc = launch_obs<float>(h, full_state, lcd))) return rc;
+  // the stream this step is queued on: the handle's own, or the caller's (blcd_set_async_stream) - then the step sits between the
+  // caller's kernels with no hand-off between streams at all
+  hipStream_t own = h->stream, T = h->asyncAdopt ? h->asyncStream : own;
+  if (h->pending && h->pendingStream != T) {   // asynchronous work queued on the other stream first
+    if (!h->evExt) HIPCHK(hipEventCreateWithFlags(&h->evExt, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->evExt, h->pendingStream));
+    HIPCHK(hipStreamWaitEvent(T, h->evExt, 0));
   }
+  h->pendingStream = T;
+  h->pending = true;
+  h->lastLaunches = 0;
+  h->stream = T;                 // launch_step / launch_obs / cohort 0's sort queue on h->stream
+  int rc = rebin_if_due(h);      // (a due sort first drains T on the host: the other cohort sorts on its own stream)
+  if (!rc) rc = join_cohort_stream(h);
+  const bool fused = (h->hostScene.lcdH == 16 || (h->hostScene.lcdH == 32 && h->hostScene.nb > 7)) && h->rolloutChunk > 0 && (full_state || lcd);
+  if (!rc) {
+    if (fused) {
+      rc = launch_step(h, actions, 1, 0, 0, nullptr, nullptr, (long long)h->N * h->hostScene.nact, lcd, full_state);
+    } else {
+      rc = launch_step(h, actions, 1, 0, 0);
+      if (!rc && (full_state || lcd)) rc = launch_obs<float>(h, full_state, lcd);
+    }
+  }
+  h->stream = own;
+  if (rc) return rc;
   h->stepsSinceRebin += 1;
-  h->asyncPending = true;
-  return BLCD_OK;   // queued on blcd_stream(h); a fault this step raises is reported by the next synchronising call
+  h->pendingStream = T;          // (rebin_if_due may have drained it: this step is queued behind that)
+  h->pending = true;
+  return BLCD_OK;   // queued; a fault this step raises is reported by the next synchronising call
 }
 
 static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out, int lcdBits);
@@ -1583,11 +1631,8 @@ int blcd_rollout_bits(blcd_handle h, const float* actions, int32_t T, uint8_t* l
 }
 static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t* lcd_out, float* obs_out, int lcdBits) {
   if (!h || T < 1) return fail(BLCD_ERR_INVALID, "blcd_rollout: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
-  if (h->asyncPending) {   // the cohorts' streams are not ordered behind an asynchronous step that is still queued on the handle's
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->asyncPending = false;
-  }
+  if (int rcEnter = enter(h)) return rcEnter;
+  if (int rc = drain_async(h)) return rc;   // the cohorts' streams are not ordered behind an asynchronous step that is still queued
   const int nact = h->hostScene.nact, nobs = h->hostScene.nobs;
   const size_t lcdStep = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW / (lcdBits ? 8 : 1);
   const size_t obsStep = (size_t)h->N * nobs;
@@ -1735,7 +1780,7 @@ static int rollout_impl(blcd_handle h, const float* actions, int32_t T, uint8_t*
 int blcd_get_obs(blcd_handle h, void* full_state, int32_t dtype, uint8_t* lcd) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_get_obs: bad handle");
   if (dtype != 0 && dtype != 1) return fail(BLCD_ERR_INVALID, "blcd_get_obs: dtype must be 0 (f32) or 1 (f64)");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const size_t obsBytes = (size_t)h->N * h->hostScene.nobs * (dtype ? 8 : 4);
   const size_t lcdBytes = (size_t)h->N * h->hostScene.lcdH * h->hostScene.lcdW;
   void *dObs, *dLcd;
@@ -1776,7 +1821,7 @@ int blcd_goal_set(blcd_handle h, const blcd_goal_desc* g, const int32_t* idxs, i
   for (int i = 0; i < (g->mode == 0 ? g->n_idx : 0); ++i)
     if (g->idxs[i] < 0 || g->idxs[i] >= h->hostScene.nobs) return fail(BLCD_ERR_INVALID, "blcd_goal_set: index outside full_state");
   if (g->mode == 1 && !goal_lcd) return fail(BLCD_ERR_INVALID, "blcd_goal_set: mode 1 needs goal_lcd");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   int rc;
   if ((rc = goal_buffers(h))) return rc;
   h->goal = *g;
@@ -1854,7 +1899,7 @@ int blcd_render_poses_ex(blcd_handle h, const float* poses, const int32_t* shape
                          int32_t mode, uint8_t* out) {
   if (!h || !poses || !out || m < 1 || width < 1 || height < 1 || width > 4096 || height > 4096 || (mode != 0 && mode != 1))
     return fail(BLCD_ERR_INVALID, "blcd_render_poses_ex: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   {
     std::lock_guard<std::mutex> lock(g_lutMutex);
     if (g_lutAmax < 0) return fail(BLCD_ERR_INVALID, "blcd_render_poses_ex: call blcd_set_ellipse_rgb_lut first (boxlcd_amd/ellipse_rgb_lut.bin)");
@@ -1891,7 +1936,7 @@ int blcd_goal_seed(blcd_handle h, const int32_t* idxs, int32_t n) {
   if (!h || !h->goalSet) return fail(BLCD_ERR_INVALID, "blcd_goal_seed: no goal installed (blcd_goal_set)");
   if (!idxs) n = h->N;
   if (n < 1 || n > h->N) return fail(BLCD_ERR_INVALID, "blcd_goal_seed: bad count");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const void* dIdx;
   int rc;
   if ((rc = in_ptr(h, 0, idxs, (size_t)n * sizeof(int32_t), &dIdx))) return rc;
@@ -1902,7 +1947,7 @@ int blcd_goal_seed(blcd_handle h, const int32_t* idxs, int32_t n) {
 
 int blcd_goal_eval(blcd_handle h, double* rew, uint8_t* done, double* delta) {
   if (!h || !h->goalSet) return fail(BLCD_ERR_INVALID, "blcd_goal_eval: no goal installed (blcd_goal_set)");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   void *dRew, *dDone, *dDelta;
   int rc;
   if ((rc = out_ptr(h, 0, rew, (size_t)h->N * sizeof(double), &dRew))) return rc;
@@ -1918,7 +1963,7 @@ int blcd_goal_eval(blcd_handle h, double* rew, uint8_t* done, double* delta) {
 
 int blcd_render_poses(blcd_handle h, const float* poses, const int32_t* shape_sel, int32_t m, uint8_t* lcd) {
   if (!h || !poses || !lcd || m < 1) return fail(BLCD_ERR_INVALID, "blcd_render_poses: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const int nb = h->hostScene.nb;
   const size_t lcdBytes = (size_t)m * h->hostScene.lcdH * h->hostScene.lcdW;
   const void *dPoses, *dSel;
@@ -1941,7 +1986,7 @@ int blcd_render_poses(blcd_handle h, const float* poses, const int32_t* shape_se
 
 int blcd_get_poses(blcd_handle h, float* poses) {
   if (!h || !poses) return fail(BLCD_ERR_INVALID, "blcd_get_poses: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const size_t bytes = (size_t)h->N * h->hostScene.nb * 4 * sizeof(float);
   void* d;
   int rc;
@@ -1954,7 +1999,7 @@ int blcd_get_poses(blcd_handle h, float* poses) {
 
 int blcd_get_shape_sel(blcd_handle h, int32_t* shape_sel) {
   if (!h || !shape_sel) return fail(BLCD_ERR_INVALID, "blcd_get_shape_sel: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const size_t bytes = (size_t)h->N * h->hostScene.nb * sizeof(int32_t);
   void* d;
   int rc;
@@ -1981,7 +2026,7 @@ int blcd_get_state(blcd_handle h, void* blob, size_t* size) {
     return BLCD_OK;
   }
   if (*size < need) return fail(BLCD_ERR_INVALID, "blcd_get_state: buffer too small");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   StateHeader hd = {0x44434c42u, BLCD_VERSION, h->N, h->hostScene.nb, h->hostScene.nj, h->hostScene.np, (uint64_t)h->words, h->envIdBase};
   std::memcpy(blob, &hd, sizeof(hd));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2003,7 +2048,7 @@ int blcd_set_state(blcd_handle h, const void* blob, size_t size) {
   if (hd.version != BLCD_VERSION) return fail(BLCD_ERR_INVALID, "blcd_set_state: snapshot written by another library version");
   if (size != need || hd.n != h->N || hd.nb != h->hostScene.nb || hd.nj != h->hostScene.nj || hd.np != h->hostScene.np || hd.words != h->words)
     return fail(BLCD_ERR_INVALID, "blcd_set_state: snapshot belongs to a different scene/batch/build");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   int rc;
   if ((rc = sampler_buffers(h))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2020,7 +2065,7 @@ int blcd_set_state(blcd_handle h, const void* blob, size_t size) {
 
 int blcd_get_faults(blcd_handle h, int32_t* flags) {
   if (!h || !flags) return fail(BLCD_ERR_INVALID, "blcd_get_faults: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const size_t bytes = (size_t)h->N * sizeof(int32_t);
   int rc = ensure_stage(h, 3, bytes);
   if (rc) return rc;
@@ -2033,9 +2078,9 @@ int blcd_get_faults(blcd_handle h, int32_t* flags) {
 
 int blcd_sync(blcd_handle h) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_sync: bad handle");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->asyncPending = false;
+  h->pending = false;              // enter() has put whatever was pending behind the handle's stream
   return BLCD_OK;
 }
 void* blcd_stream(blcd_handle h) { return h ? (void*)h->stream : nullptr; }
@@ -2049,7 +2094,7 @@ int blcd_last_kernel_ms(blcd_handle h, float* ms, int32_t* launches) {
 
 int blcd_sched_stats(blcd_handle h, uint64_t* out8) {
   if (!h || !out8) return fail(BLCD_ERR_INVALID, "blcd_sched_stats: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   int rc;
   if ((rc = join_cohort_stream(h))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2065,7 +2110,7 @@ int blcd_debug_wave_times(blcd_handle h, uint64_t* out, int32_t cap) {
   if (!h->waveTimes) return fail(BLCD_ERR_UNSUPPORTED, "build with BLCD_DEFS=-DBLCD_WAVETIMES and set BLCD_WAVETIMES=1 before blcd_create");
   int nw = (h->N + h->lanes - 1) / h->lanes;
   if (nw * 9 > cap) nw = cap / 9;
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(out, h->waveTimes, (size_t)nw * 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(h->waveTimes, 0, (size_t)nw * 9 * sizeof(uint64_t)));
@@ -2073,7 +2118,7 @@ int blcd_debug_wave_times(blcd_handle h, uint64_t* out, int32_t cap) {
 }
 int blcd_debug_world_step(blcd_handle h, int32_t n) {
   if (!h || n < 0) return fail(BLCD_ERR_INVALID, "blcd_debug_world_step: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   int rc = launch_step(h, nullptr, 0, n, 0);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2081,7 +2126,7 @@ int blcd_debug_world_step(blcd_handle h, int32_t n) {
 }
 int blcd_debug_set_motor_speeds(blcd_handle h, const float* actions) {
   if (!h) return fail(BLCD_ERR_INVALID, "blcd_debug_set_motor_speeds: bad handle");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const void* dAct;
   int rc;
   if ((rc = in_ptr(h, 0, actions, (size_t)h->N * h->hostScene.nact * sizeof(float), &dAct))) return rc;
@@ -2091,7 +2136,7 @@ int blcd_debug_set_motor_speeds(blcd_handle h, const float* actions) {
 }
 int blcd_debug_dump(blcd_handle h, float* bodies, float* joints, float* pairs) {
   if (!h || !bodies || !joints || !pairs) return fail(BLCD_ERR_INVALID, "blcd_debug_dump: bad arguments");
-  HIPCHK(hipSetDevice(h->device));
+  if (int rcEnter = enter(h)) return rcEnter;
   const DevScene& S = h->hostScene;
   size_t bb = (size_t)h->N * S.nb * BLCD_BODY_STATE_FLOATS * 4;
   size_t jb = (size_t)h->N * (S.nj > 0 ? S.nj : 1) * BLCD_JOINT_STATE_FLOATS * 4;

@@ -589,14 +589,16 @@ class BatchedWorldEnv(_EnvSpec):
     done bool [N], timeout bool [N]) - ONE call (blcd_step_obs: the step kernel writes the observation row and the frame itself),
     one stream synchronisation, nothing crosses PCIe.
     sync=False: no host synchronisation at all (blcd_step_obs_async) - the step is ordered between the torch work before and after it
-    on the device, the call returns while it runs; device faults are then only seen through `faults()`."""
+    on the device, the call returns while it runs; device faults are then only seen through `faults()`.
+    sync='inline': as False, with the step queued ON torch's current stream (blcd_set_async_stream) - no hand-off between streams either;
+    meant for the small scene classes (a stream's hardware queue reserves scratch for the largest kernel it has run)."""
     tb = self._torch_bufs()
     a = actions.contiguous() if actions.dtype == tb['full_state'].dtype else actions.float().contiguous()
     assert a.is_cuda and tuple(a.shape) == (self.num_envs, self.act_size)
-    if sync:
+    if not (sync is False or (isinstance(sync, str) and sync == 'inline')):
       self._step_handle(a, tb['full_state'], tb['lcd'])        # blcd_step_obs; a faulted environment does not abort the batch: see faults()
     else:
-      self._handle().step_obs_async(a, tb['full_state'], tb['lcd'])
+      self._handle().step_obs_async(a, tb['full_state'], tb['lcd'], inline=isinstance(sync, str))
     self._ep_lag += 1                  # the host clocks are brought up to date when something reads them (_flush_ep)
     if self._ep_same is not None:      # every environment at the same step of its episode: a constant, no kernel
       self._ep_same += 1

@@ -172,6 +172,12 @@ int blcd_step_obs(blcd_handle h, const float* actions, float* full_state, uint8_
  * raised by the step is not reported here: it stays readable through blcd_get_faults and is returned by the next synchronising
  * step / rollout call. */
 int blcd_step_obs_async(blcd_handle h, const float* actions, float* full_state, uint8_t* lcd);
+/* The stream blcd_step_obs_async queues on: adopt = 0 (default) = the handle's own stream; adopt = 1 = `stream`, a hipStream_t of the
+ * caller (NULL = the device's default stream, which is what torch uses unless told otherwise): the step runs ON that stream, between the caller's kernels, with no hand-off between streams (a Bounce-100k step is 61 us of kernel; two cross-stream
+ * waits cost half as much again).  Every other entry point keeps the handle's own stream and is ordered behind steps queued on the adopted
+ * one.  Opt-in: each hardware queue reserves scratch for the largest kernel it has run, so adopt a stream for the small
+ * scene classes; the caller keeps the stream alive until blcd_sync / blcd_destroy.  Drains pending asynchronous steps. */
+int blcd_set_async_stream(blcd_handle h, void* stream, int32_t adopt);
 
 /* Fused rollout, replaces the inner loop of research/data.py:56-61 (`for j in range(ep_len): venv.step(act)`):
  * T env-steps with per-step actions [T][n_envs][n_act]; per-step outputs (any may be NULL):

@@ -240,13 +240,13 @@ def test_episode_clocks_of_the_device_loop():
   z = np.zeros((n, a.act_size), np.float32)
   zt = torch.zeros((n, a.act_size), device='cuda')
   rs = np.random.RandomState(0)
-  script = ['t', 't', 'p', 't', 'n', 't', 'T', 'P', 'T', 't', 't', 'f', 't', 'T', 'n', 't', 't', 'p', 't', 'P', 't', 't', 't', 't', 'F', 't', 't']
+  script = ['t', 't', 'p', 't', 'n', 't', 'T', 'P', 'I', 't', 'I', 'f', 't', 'T', 'n', 'I', 't', 'p', 'I', 'P', 't', 'T', 'I', 't', 'F', 'I', 't']
   for k, op in enumerate(script):
-    if op in 'tTn':
+    if op in 'tTIn':
       if op == 'n':
         _, _, da, _ = a.step(z)
       else:
-        _, _, da, _ = a.step_torch(zt, sync=(op == 't'))
+        _, _, da, _ = a.step_torch(zt, sync={'t': True, 'T': False, 'I': 'inline'}[op])
         da = da.cpu().numpy()
       _, _, db, _ = b.step(z)
       assert (np.asarray(da) == db).all(), (k, op)
@@ -267,8 +267,9 @@ def test_episode_clocks_of_the_device_loop():
   a.close(); b.close()
 
 
+@pytest.mark.parametrize('mode', [False, 'inline'])
 @pytest.mark.parametrize('name,n,T', [('Bounce', 70_000, 130), ('Urchin', 300, 40), ('Object2', 66_000, 25)])
-def test_asynchronous_step_loop_equals_the_synchronous_one(name, n, T):
+def test_asynchronous_step_loop_equals_the_synchronous_one(name, n, T, mode):
   """step_torch(sync=False) = blcd_step_obs_async: no host synchronisation anywhere in the loop - the step is ordered on the device
   between the torch kernels that produce its actions and those that consume its outputs.  A 'policy' that reads the previous
   observation (so outputs feed inputs) drives an asynchronous env and a synchronous twin: same observations at every step, same
@@ -281,7 +282,9 @@ def test_asynchronous_step_loop_equals_the_synchronous_one(name, n, T):
   policy = lambda o: torch.tanh(o['full_state'].nan_to_num() @ W)[:, :a.act_size].contiguous()
   snaps = []
   for t in range(T):
-    oa, _, _, _ = a.step_torch(policy(oa), sync=False)
+    oa, _, _, _ = a.step_torch(policy(oa), sync=mode)           # 'inline': queued ON torch's stream (blcd_set_async_stream)
+    if mode == 'inline' and t == T // 2:
+      assert not a.faults().any()                                # a synchronising call on the handle's own stream in between
     snaps.append((oa['full_state'].clone(), oa['lcd'].clone()))           # queued behind the step on torch's stream
   for t in range(T):
     ob, _, _, _ = b.step_torch(policy(ob))

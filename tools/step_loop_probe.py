@@ -8,7 +8,7 @@ name, N, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 env = B.BatchedWorldEnv(name, N, seed=4242)
 env.reset_torch()
 a = torch.empty((N, env.act_size), dtype=torch.float32, device='cuda')
-for sync in (True, False):
+for sync in (True, False, 'inline'):
   for _ in range(10):
     env.step_torch(a.uniform_(-1, 1), sync=sync)
   torch.cuda.synchronize()
