@@ -83,6 +83,7 @@ def pmc_blocks(env_name, n_envs, dispatches_per_chunk=1, steps_per_launch=None):
                 'waiting_frac_of_wave_cycles': c['SQ_WAIT_ANY']['mean'] / w if 'SQ_WAIT_ANY' in c else None,
                 'lanes_per_valu_inst': (c['SQ_THREAD_CYCLES_VALU']['mean'] / c['SQ_ACTIVE_INST_VALU']['mean']) if 'SQ_THREAD_CYCLES_VALU' in c else None,
                 'waves_per_dispatch': c['SQ_WAVES']['mean'] if 'SQ_WAVES' in c else None,
+                'lanes_note': 'active lanes per VALU instruction INCLUDING shadow lanes: lanes beyond a narrow wave\'s width run as copies of its last environment (no stores) so that every wave keeps the coalesced frame path; an under-subscribed batch of w environments per wave carries w / 64 of this figure',
                 'source': f'{path} ({basis}; rocprofv3 --pmc SQ_* pass of the same command; profile-derived)'}
       return traffic, detail, valu
     except Exception as ex:
