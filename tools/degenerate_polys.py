@@ -5,6 +5,9 @@ For each recording: replay the oracle from the recorder's inputs (tests/replay.p
 (8x RGB view exact) and every polygon body: LCD-scale vertices float64(float32 world) / WIDTH * lcd_w truncated toward zero
 (world_env.py:500-505).  Degenerate = all integer vertices on one row or on one column.  "drawn" = the pixels of
 the polygon's horizontal (vertical) extent that no OTHER body covers are set in the recording's LCD frame.
+NOTE: the table in profiles/r04_param_sweep.md was generated BEFORE raster variant 2 learnt the rule this table led to (horizontal edges are
+drawn from a per-row scan position that starts at 0).  "Pixels no other body covers" are taken from the oracle's own variant-2 frame, which now
+contains the two drawn feet - so today the tool lists the nine polygons the rule leaves undrawn and no longer the two it draws.
 usage: python tools/degenerate_polys.py [--md file]"""
 import os
 import sys
